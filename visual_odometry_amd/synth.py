@@ -1,0 +1,78 @@
+"""Deterministic synthetic inputs for tests and benchmarks.
+
+The datasets the reference is run on (TUM fr1_xyz, KITTI) cannot be fetched, so
+frames are generated: a layered scene of textured rectangles at different
+depths, seen by a camera that translates along +x between the two frames
+(every layer shifts left by its own integer disparity, 12-40 px, so that
+triangulated depths stay below recoverPose's 50-baseline cut-off), plus independent pixel
+noise per frame.  The two views therefore obey a real two-view geometry
+(R = I, t along x) and FAST fires densely at every pyramid level.
+"""
+import numpy as np
+
+
+def _texture(rng, h, w):
+    """Blocky high-contrast texture with corners at several scales."""
+    img = rng.integers(40, 216, size=(h // 16 + 2, w // 16 + 2)).astype(np.float32)
+    img = np.kron(img, np.ones((16, 16), np.float32))[:h, :w]
+    for cell, amp in ((8, 50.0), (4, 35.0), (2, 20.0)):
+        g = rng.integers(-1, 2, size=(h // cell + 2, w // cell + 2)).astype(np.float32)
+        img += amp * np.kron(g, np.ones((cell, cell), np.float32))[:h, :w]
+    return img
+
+
+def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0):
+    """Returns (frame_a, frame_b) as uint8 arrays of shape (height, width)."""
+    rng = np.random.default_rng(seed)
+    pad = 48
+    W = width + 2 * pad
+    a = _texture(rng, height, W)
+    b = np.roll(a, -12, axis=1)  # background: disparity 12 px
+    for _ in range(n_layers):
+        h = int(rng.integers(height // 6, height // 2))
+        w = int(rng.integers(width // 8, width // 3))
+        y = int(rng.integers(0, height - h))
+        x = int(rng.integers(pad, W - pad - w))
+        d = int(rng.integers(14, 41))
+        tex = _texture(rng, h, w)
+        a[y:y + h, x:x + w] = tex
+        b[y:y + h, x - d:x - d + w] = tex
+    a = a[:, pad:pad + width]
+    b = b[:, pad:pad + width]
+    a = a + rng.normal(0.0, noise, a.shape)
+    b = b + rng.normal(0.0, noise, b.shape)
+    return (np.clip(np.rint(a), 0, 255).astype(np.uint8),
+            np.clip(np.rint(b), 0, 255).astype(np.uint8))
+
+
+def checkerboard(height=480, width=640, cell=32, shift=0, noise_sigma=25.0, seed=0):
+    """The reference's detector/matcher test fixture (a 0/255 checkerboard with
+    additive Gaussian noise, saturated to uint8; ref:tests/test_feature_detector.cpp:11-23,
+    ref:tests/test_feature_matcher.cpp:13-33) with a seeded numpy noise source in
+    place of OpenCV's global RNG, whose stream is not reproducible here."""
+    y, x = np.mgrid[0:height, 0:width]
+    x2 = (x + shift) % width
+    img = np.where(((x2 // cell) % 2) == ((y // cell) % 2), 255, 0).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    # cv::randn into CV_8U saturates negative noise to 0, so only the positive
+    # half is added (test_image_ += noise).
+    noise = np.clip(np.rint(rng.normal(0.0, noise_sigma, img.shape)), 0, 255)
+    return np.clip(img + noise, 0, 255).astype(np.uint8)
+
+
+def descriptors(seed, n, dup_fraction=0.01):
+    """n random 256-bit descriptors with a fraction of planted near-duplicates."""
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k = int(n * dup_fraction)
+    if k > 0 and n > 1:
+        src = rng.integers(0, n, size=k)
+        dst = rng.integers(0, n, size=k)
+        d[dst] = d[src]
+        flip = rng.integers(0, 32, size=k)
+        d[dst, flip] ^= (1 << rng.integers(0, 8, size=k)).astype(np.uint8)
+    return d
+
+
+TUM_K = (517.3, 516.5, 318.6, 255.3)         # ref:data/tum/README.md:57-58
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # ref:data/README.md:30-33
