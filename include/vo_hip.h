@@ -1,0 +1,155 @@
+/* C ABI of the MI355X (gfx950) visual-odometry front end.
+ *
+ * The reference has no FFI seam of its own: its hot path is three free C++
+ * functions compiled into one static library.  This header is the boundary a
+ * replacement of those functions binds to; each entry point names the
+ * reference interface it stands in for.  Plain pointers and sizes only,
+ * caller-owned buffers, int status codes (0 = success).
+ *
+ * Pointers named d_* are device (HBM) addresses on the context's GPU; all
+ * others are host addresses.  Device entry points enqueue work on the
+ * context's stream and return without waiting; vo_sync() waits.  Host entry
+ * points copy in, run, copy out and return when the results are in place.
+ * A context is not thread-safe: use one per host thread and GPU.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response,
+ * octave, class_id) as filled by cv::ORB. */
+typedef struct vo_keypoint {
+    float x, y;
+    float size;
+    float angle;    /* degrees in [0,360) */
+    float response; /* Harris response */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} vo_keypoint;
+
+/* One frame pair's result of the fused pipeline (motion_estimate plus the
+ * counts the reference's benchmark reports). */
+typedef struct vo_pair_result {
+    double R[9]; /* row-major rotation */
+    double t[3]; /* unit translation */
+    int32_t inliers;
+    int32_t valid;
+    int32_t n_kp1, n_kp2;
+    int32_t n_matches;
+    int32_t ransac_iters;
+} vo_pair_result;
+
+enum {
+    VO_OK = 0,
+    VO_ERR_INVALID = 1,  /* bad argument */
+    VO_ERR_HIP = 2,      /* a HIP runtime call failed */
+    VO_ERR_CAPACITY = 3, /* an output or internal list overflowed its capacity */
+    VO_ERR_NOMEM = 4
+};
+
+/* --- context ------------------------------------------------------------- */
+int vo_ctx_create(int device, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+/* Message of the last failing call on this context ("" if none). */
+const char* vo_last_error(const vo_ctx* ctx);
+/* hipStream_t the context enqueues on (as void*). */
+void* vo_ctx_stream(vo_ctx* ctx);
+int vo_sync(vo_ctx* ctx);
+/* Milliseconds (HIP events on the context's stream) the most recent call
+ * spent in its dominant kernel: FAST for detection, the top-2 kernel for
+ * matching.  -1 if timing was not enabled with vo_set_timing(ctx, 1). */
+int vo_set_timing(vo_ctx* ctx, int enabled);
+float vo_last_kernel_ms(vo_ctx* ctx, int which);
+
+/* --- detect_features / detect_keypoints_only -------------------------------
+ * Replaces visual_odometry::detect_features (ref:src/feature_detector.cpp:12-18,
+ * decl ref:include/visual_odometry/feature_detector.hpp:36) and, with
+ * desc_out == NULL, detect_keypoints_only (ref:src/feature_detector.cpp:20-27):
+ * ORB with nfeatures = max_features and OpenCV's other defaults (scale 1.2,
+ * 8 levels, edge 31, FAST 20, Harris score, patch 31, WTA_K 2).
+ * img: rows x cols 8-bit grayscale, `step` bytes per row.  Keypoints come out
+ * per pyramid level, in raster order inside a level.  rows*cols == 0 yields
+ * n_out = 0.  More than `cap` keypoints -> VO_ERR_CAPACITY. */
+int vo_orb_detect(vo_ctx* ctx, const uint8_t* img, int rows, int cols, int step, int max_features,
+                  vo_keypoint* kps_out, uint8_t* desc_out /* cap x 32 or NULL */, int cap, int* n_out);
+
+/* Batched, device-resident form of the same: n_images images of identical
+ * shape, image i at d_imgs + i*image_stride.  Image i's keypoints land at
+ * d_kps + i*cap, descriptors at d_desc + i*cap*32 (d_desc may be NULL), its
+ * count at d_counts[i]. */
+int vo_orb_detect_batch_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_images, int rows, int cols,
+                            int step, size_t image_stride, int max_features, vo_keypoint* d_kps,
+                            uint8_t* d_desc, int cap, int32_t* d_counts);
+
+/* --- match_features ---------------------------------------------------------
+ * Replaces the cv::BFMatcher(NORM_HAMMING, crossCheck=false)::knnMatch(k=2)
+ * call of visual_odometry::match_features (ref:src/feature_matcher.cpp:26-30):
+ * for every 32-byte query row the two nearest train rows by Hamming distance,
+ * nearest first, ties to the lower train index.  idx2/dist2 are nq x 2; a
+ * missing neighbour (nt < 2) is idx -1, dist -1. */
+int vo_hamming_knn2(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
+                    int32_t* dist2);
+int vo_hamming_knn2_dev(vo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                        int32_t* d_idx2, int32_t* d_dist2);
+
+/* The whole of match_features (ref:src/feature_matcher.cpp:15-42): kNN(2),
+ * Lowe ratio test `d0 < ratio * d1` in float32, survivors in query order.
+ * Outputs hold up to nq entries: query index, train index, distance (the
+ * fields of cv::DMatch; imgIdx is always 0).  Empty inputs give *n_out = 0. */
+int vo_match_ratio(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
+                   int32_t* query_idx, int32_t* train_idx, float* distance, int* n_out);
+
+/* --- estimate_motion -----------------------------------------------------------
+ * Replaces visual_odometry::estimate_motion (ref:src/motion_estimator.cpp:44-95):
+ * cv::findEssentialMat(RANSAC, confidence, threshold, 1000 iterations, 5-point
+ * solver, Sampson error) then cv::recoverPose (cheirality, depth < 50), with
+ * the reference's validity rules (fewer than 5 points, no model, or fewer than
+ * 10 pose inliers -> *valid = 0 and *inliers = 0).  p1/p2: n x 2 float pixel
+ * coordinates.  K = {fx, fy, cx, cy}.  fixed_iters > 0 evaluates exactly that
+ * many hypotheses instead of the adaptive count.  mask (n bytes, may be NULL)
+ * receives the pose inlier mask. */
+int vo_estimate_motion(vo_ctx* ctx, const float* p1, const float* p2, int n, const double K[4],
+                       double threshold, double confidence, int fixed_iters, double R[9],
+                       double t[3], int* inliers, int* valid, uint8_t* mask);
+
+/* RANSAC stage alone, for parity checks under a shared hypothesis set:
+ * returns the winning essential matrix, its inlier mask and count, the number
+ * of iterations run, and (samples != NULL, max(1000, fixed_iters) x 5 ints) the
+ * 5-point index sets in the order drawn. */
+int vo_find_essential(vo_ctx* ctx, const float* p1, const float* p2, int n, const double K[4],
+                      double threshold, double confidence, int fixed_iters, double E[9],
+                      uint8_t* mask, int* good, int* iters_run, int32_t* samples);
+
+/* --- fused pipeline --------------------------------------------------------------
+ * detect x2 + match + estimate_motion for n_pairs frame pairs, i.e.
+ * match_images_orb (ref:src/image_matcher.cpp:71-81) followed by estimate_motion
+ * as the reference's main loop runs them (ref:src/main.cpp:162-170), with every
+ * intermediate kept in HBM.  Pair p uses images 2p and 2p+1 of d_imgs.
+ * d_results: n_pairs records in device memory. */
+int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
+                          size_t image_stride, int max_features, float ratio, const double K[4],
+                          double threshold, double confidence, int fixed_iters,
+                          vo_pair_result* d_results);
+
+/* --- inspection (parity tests) ---------------------------------------------------
+ * Copies pyramid level `level` of image `image` of the most recent detect call
+ * (blurred != 0: the 7x7 Gaussian-blurred copy the descriptors sample) to
+ * host memory, tightly packed w x h. */
+int vo_debug_level(vo_ctx* ctx, int image, int level, int blurred, uint8_t* out, int* w, int* h);
+/* FAST candidates (after non-max suppression and the 31-pixel border filter)
+ * of one level of the most recent detect call as (x, y, score) triples, in no
+ * particular order.  Returns the count in *n_out. */
+int vo_debug_candidates(vo_ctx* ctx, int image, int level, int32_t* out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

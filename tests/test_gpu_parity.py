@@ -1,0 +1,257 @@
+"""GPU parity suite: every stage of the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.  Integer / byte / index
+results must be bit-exact; pose tolerances are written in the tests."""
+import os
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KITTI_K = synth.KITTI_K
+TUM_K = synth.TUM_K
+
+
+def _rot_err_deg(R1, R2):
+    c = (np.trace(R1.T @ R2) - 1) / 2
+    return np.degrees(np.arccos(np.clip(c, -1, 1)))
+
+
+# ------------------------------------------------------------------ Hamming kNN(2)
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (5, 1), (64, 64), (777, 1234), (2000, 2000), (300, 257),
+                                   (4100, 513)])
+def test_knn2_matches_oracle(ctx, oracle, nq, nt):
+    q = synth.descriptors(100 + nq, nq, dup_fraction=0.2)
+    t = synth.descriptors(200 + nt, nt, dup_fraction=0.3)
+    if nt > 100 and nq > 50:
+        t[-50:] = q[:50]                      # exact duplicates: distance-0 ties
+        t[7:57] = q[:50]
+    gi, gd = ctx.hamming_knn2(q, t)
+    oi, od = oracle.knn2(q, t)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gd, od)
+
+
+def test_knn2_empty_train(ctx):
+    q = synth.descriptors(1, 10)
+    gi, gd = ctx.hamming_knn2(q, np.zeros((0, 32), np.uint8))
+    assert np.all(gi == -1) and np.all(gd == -1)
+
+
+def test_knn2_beyond_65536_train_rows(ctx, oracle):
+    q = synth.descriptors(31, 1500, dup_fraction=0.1)
+    t = synth.descriptors(32, 70000, dup_fraction=0.05)
+    t[69000:69100] = q[:100]
+    t[100:200] = q[:100]
+    gi, gd = ctx.hamming_knn2(q, t)
+    oi, od = oracle.knn2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.75, 0.9])
+def test_match_ratio_matches_oracle(ctx, oracle, ratio):
+    q = synth.descriptors(41, 1800, dup_fraction=0.05)
+    t = q.copy()
+    rng = np.random.default_rng(42)
+    flips = rng.integers(0, 256, size=(len(t), 40))
+    for k in range(40):                       # noisy copies: many true matches, graded distances
+        sel = rng.random(len(t)) < 0.7
+        t[sel, flips[sel, k] // 8] ^= (1 << (flips[sel, k] % 8)).astype(np.uint8)
+    t = t[rng.permutation(len(t))]
+    gq, gt, gd = ctx.match_ratio(q, t, ratio)
+    oq, ot, od = oracle.match(q, t, ratio)
+    assert len(oq) > 100
+    assert np.array_equal(gq, oq) and np.array_equal(gt, ot) and np.array_equal(gd, od)
+
+
+def test_match_empty_descriptors(ctx):
+    d = synth.descriptors(5, 20)
+    e = np.zeros((0, 32), np.uint8)
+    assert len(ctx.match_ratio(e, d)[0]) == 0
+    assert len(ctx.match_ratio(d, e)[0]) == 0
+
+
+# ------------------------------------------------------------------ ORB stages
+IMAGES = {
+    "synth640": lambda: synth.frame_pair(7)[0],
+    "checker": lambda: synth.checkerboard(seed=9),
+    "kitti": lambda: synth.frame_pair(8, height=376, width=1241)[0],
+    "odd": lambda: synth.frame_pair(9, height=301, width=423)[1],
+}
+
+
+@pytest.mark.parametrize("name", list(IMAGES))
+def test_pyramid_blur_fast_stages(ctx, oracle, name):
+    img = IMAGES[name]()
+    ctx.orb_detect(img, 1000)
+    for l in range(8):
+        lv = ctx.debug_level(0, l)
+        ol = oracle.pyramid_level(img, l)
+        assert lv.shape == ol.shape
+        assert np.array_equal(lv, ol), f"pyramid level {l}"
+        assert np.array_equal(ctx.debug_level(0, l, blurred=True), oracle.pyramid_level(img, l, blurred=True)), \
+            f"blurred level {l}"
+        cand = ctx.debug_candidates(0, l)
+        h, w = ol.shape
+        of = oracle.fast(ol)
+        keep = (of[:, 0] >= 31) & (of[:, 0] < w - 31) & (of[:, 1] >= 31) & (of[:, 1] < h - 31) if len(of) else []
+        of = of[keep] if len(of) else of
+        got = sorted(map(tuple, cand.tolist()))
+        exp = sorted(map(tuple, of.tolist()))
+        assert got == exp, f"FAST candidates level {l}: {len(got)} vs {len(exp)}"
+
+
+@pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 1000), ("checker", 2000), ("checker", 100),
+                                        ("kitti", 4000), ("odd", 500), ("synth640", 37)])
+def test_orb_detect_bit_exact(ctx, oracle, name, nfeat):
+    img = IMAGES[name]()
+    gk, gd = ctx.orb_detect(img, nfeat)
+    ok, od = oracle.orb_detect(img, nfeat)
+    assert len(gk) == len(ok) and len(gk) > 0
+    for f in ("octave", "x", "y", "size", "response", "angle", "class_id"):
+        assert np.array_equal(gk[f], ok[f]), f"keypoint field {f}"
+    assert gk.tobytes() == ok.tobytes()
+    assert np.array_equal(gd, od)
+    gk2, none = ctx.orb_detect(img, nfeat, want_desc=False)     # detect_keypoints_only
+    assert none is None and gk2.tobytes() == ok.tobytes()
+
+
+def test_orb_strided_input(ctx, oracle):
+    big = np.zeros((480, 700), np.uint8)
+    img = synth.frame_pair(12)[0]
+    big[:, :640] = img
+    view = big[:, :640]                       # row step 700, not a multiple of 4 images wide
+    import ctypes as C
+    from visual_odometry_amd import capi
+    kps = np.zeros(4096, capi.KP_DTYPE)
+    desc = np.zeros((4096, 32), np.uint8)
+    n = C.c_int()
+    rc = ctx.lib.vo_orb_detect(ctx.h, big.ctypes.data_as(C.c_void_p), 480, 640, 700, 1000,
+                               kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), 4096, C.byref(n))
+    assert rc == 0
+    ok, od = oracle.orb_detect(np.ascontiguousarray(view), 1000)
+    assert kps[: n.value].tobytes() == ok.tobytes() and np.array_equal(desc[: n.value], od)
+
+
+def test_detector_reference_contract(ctx):
+    # ref:tests/test_feature_detector.cpp:28-102
+    img = synth.checkerboard(seed=1)
+    k, d = ctx.orb_detect(img, 2000)
+    assert len(k) > 0 and d.shape == (len(k), 32)
+    assert len(ctx.orb_detect(img, 100, want_desc=False)[0]) <= 100
+    assert len(ctx.orb_detect(np.zeros((0, 0), np.uint8))[0]) == 0
+    assert len(ctx.orb_detect(np.full((480, 640), 128, np.uint8))[0]) < 10
+
+
+def test_capacity_overflow_is_loud(ctx):
+    from visual_odometry_amd import capi
+    img = synth.frame_pair(7)[0]
+    with pytest.raises(capi.VoError):
+        ctx.orb_detect(img, 2000, cap=100)
+
+
+# ------------------------------------------------------------------ RANSAC / pose
+def _matched_points(oracle, seed, nfeat=2000):
+    a, b = synth.frame_pair(seed)
+    ka, da = oracle.orb_detect(a, nfeat)
+    kb, db = oracle.orb_detect(b, nfeat)
+    qi, ti, _ = oracle.match(da, db)
+    return np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_find_essential_shared_hypotheses(ctx, oracle, seed):
+    p1, p2 = _matched_points(oracle, seed)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, TUM_K)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, TUM_K)
+    assert git == oit
+    assert np.array_equal(gsamp, osamp)                        # identical hypothesis index sets
+    assert gg == og
+    assert np.array_equal(gm, om)
+    s = 1.0 if np.sum(gE * oE) > 0 else -1.0
+    assert np.max(np.abs(gE - s * oE)) < 1e-8
+
+
+@pytest.mark.parametrize("fixed", [64, 700])
+def test_find_essential_fixed_hypothesis_count(ctx, oracle, fixed):
+    p1, p2 = _matched_points(oracle, 24, 1000)
+    rng = np.random.default_rng(3)
+    bad = rng.random(len(p1)) < 0.4                            # 40 % gross outliers
+    p2 = p2.copy()
+    p2[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2)).astype(np.float32)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, TUM_K, fixed_iters=fixed)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, TUM_K, fixed_iters=fixed)
+    assert git == oit == fixed
+    assert np.array_equal(gsamp, osamp)
+    assert gg == og and np.array_equal(gm, om)
+
+
+@pytest.mark.parametrize("name", ["forward", "rotation"])
+def test_reference_motion_scenes(ctx, oracle, name):
+    # ref:tests/test_motion_estimator.cpp:61-102 plus agreement with the oracle and the ground truth
+    z = np.load(os.path.join(GOLD, f"motion_scene_{name}.npz"))
+    g = ctx.estimate_motion(z["p1"], z["p2"], KITTI_K)
+    o = oracle.estimate_motion(z["p1"], z["p2"], KITTI_K)
+    assert g["valid"] and g["inliers"] > 50
+    if name == "forward":
+        assert g["t"][2] > 0.9
+    assert g["inliers"] == o["inliers"]
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01                 # degrees
+    assert np.linalg.norm(g["t"] - o["t"]) < 1e-4              # unit-translation error
+    assert _rot_err_deg(g["R"], z["R"]) < 0.01 and np.linalg.norm(g["t"] - z["t"]) < 1e-4
+
+
+@pytest.mark.parametrize("seed", [21, 25, 26])
+def test_estimate_motion_matches_oracle(ctx, oracle, seed):
+    p1, p2 = _matched_points(oracle, seed)
+    g = ctx.estimate_motion(p1, p2, TUM_K)
+    o = oracle.estimate_motion(p1, p2, TUM_K)
+    assert g["valid"] == o["valid"] and g["valid"]
+    assert g["inliers"] == o["inliers"]
+    assert np.array_equal(g["mask"], o["mask"])
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01
+    assert np.linalg.norm(g["t"] - o["t"]) < 1e-4
+
+
+def test_motion_validity_rules(ctx):
+    # ref:src/motion_estimator.cpp:52-54,83-85
+    p1 = np.array([[100, 100], [200, 200], [300, 300]], np.float32)
+    r = ctx.estimate_motion(p1, p1 + np.float32(10), KITTI_K)
+    assert not r["valid"] and r["inliers"] == 0
+    rng = np.random.default_rng(0)                              # pure noise: no consistent model
+    a = rng.uniform(0, 600, (40, 2)).astype(np.float32)
+    b = rng.uniform(0, 600, (40, 2)).astype(np.float32)
+    r = ctx.estimate_motion(a, b, KITTI_K)
+    assert r["inliers"] == 0 or r["valid"]
+
+
+# ------------------------------------------------------------------ fused pipeline
+def test_pipeline_pairs_matches_oracle(ctx, oracle):
+    import torch
+    from visual_odometry_amd import capi
+    n_pairs = 3
+    frames = []
+    for p in range(n_pairs):
+        frames += list(synth.frame_pair(50 + p))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    res = torch.zeros(n_pairs * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_pairs_dev(imgs.data_ptr(), n_pairs, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                           res.data_ptr())
+    ctx.sync()
+    torch.cuda.synchronize()
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    for p in range(n_pairs):
+        a, b = frames[2 * p], frames[2 * p + 1]
+        ka, da = oracle.orb_detect(a, 2000)
+        kb, db = oracle.orb_detect(b, 2000)
+        qi, ti, _ = oracle.match(da, db)
+        p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
+        p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
+        o = oracle.estimate_motion(p1, p2, TUM_K)
+        r = out[p]
+        assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi))
+        assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"]
+        assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01
+        assert np.linalg.norm(r["t"] - o["t"]) < 1e-4

@@ -1,0 +1,207 @@
+"""ctypes binding of libvo_hip.so (the C ABI declared in include/vo_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+PAIR_DTYPE = np.dtype(
+    [("R", "<f8", (9,)), ("t", "<f8", (3,)), ("inliers", "<i4"), ("valid", "<i4"),
+     ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"), ("ransac_iters", "<i4")]
+)
+
+EXPORTS = [
+    "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
+    "vo_last_kernel_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
+    "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
+    "vo_pipeline_pairs_dev", "vo_debug_level", "vo_debug_candidates",
+]
+
+_lib = None
+
+
+class VoError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libvo_hip.so and declares its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VoError(f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, f, d, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+    lib.vo_ctx_create.argtypes = [i, C.POINTER(vp)]
+    lib.vo_ctx_destroy.argtypes = [vp]
+    lib.vo_ctx_destroy.restype = None
+    lib.vo_last_error.argtypes = [vp]
+    lib.vo_last_error.restype = C.c_char_p
+    lib.vo_ctx_stream.argtypes = [vp]
+    lib.vo_ctx_stream.restype = vp
+    lib.vo_sync.argtypes = [vp]
+    lib.vo_set_timing.argtypes = [vp, i]
+    lib.vo_last_kernel_ms.argtypes = [vp, i]
+    lib.vo_last_kernel_ms.restype = f
+    lib.vo_orb_detect.argtypes = [vp, vp, i, i, i, i, vp, vp, i, C.POINTER(i)]
+    lib.vo_orb_detect_batch_dev.argtypes = [vp, vp, i, i, i, i, sz, i, vp, vp, i, vp]
+    lib.vo_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp, vp]
+    lib.vo_hamming_knn2_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
+    lib.vo_match_ratio.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, C.POINTER(i)]
+    lib.vo_estimate_motion.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
+    lib.vo_find_essential.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
+    lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
+    lib.vo_debug_level.argtypes = [vp, i, i, i, vp, C.POINTER(i), C.POINTER(i)]
+    lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU context (stream + workspace).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.vo_ctx_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise VoError(f"vo_ctx_create(device={device}) failed with code {rc}")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VoError(f"{what} failed (code {rc}): {self.lib.vo_last_error(self.h).decode()}")
+
+    @property
+    def stream(self):
+        return self.lib.vo_ctx_stream(self.h)
+
+    def sync(self):
+        self._check(self.lib.vo_sync(self.h), "vo_sync")
+
+    def set_timing(self, on=True):
+        self.lib.vo_set_timing(self.h, int(on))
+
+    def last_kernel_ms(self, which):
+        return float(self.lib.vo_last_kernel_ms(self.h, which))
+
+    # ---- host-buffer entry points ------------------------------------------------
+    def orb_detect(self, img, max_features=2000, want_desc=True, cap=None):
+        if img is None or img.size == 0:
+            n = C.c_int(-1)
+            self._check(self.lib.vo_orb_detect(self.h, None, 0, 0, 0, max_features, None, None, 1, C.byref(n)),
+                        "vo_orb_detect")
+            return np.zeros(0, KP_DTYPE), (np.zeros((0, 32), np.uint8) if want_desc else None)
+        img = np.ascontiguousarray(img, np.uint8)
+        rows, cols = img.shape
+        cap = cap or max_features + 8 * 256
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8) if want_desc else None
+        n = C.c_int()
+        self._check(self.lib.vo_orb_detect(self.h, _p(img), rows, cols, img.strides[0], int(max_features), _p(kps),
+                                           _p(desc), cap, C.byref(n)), "vo_orb_detect")
+        return kps[: n.value].copy(), (desc[: n.value].copy() if want_desc else None)
+
+    def debug_level(self, image, level, blurred=False):
+        out = np.zeros(4096 * 4096 // 4, np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._check(self.lib.vo_debug_level(self.h, image, level, int(blurred), _p(out), C.byref(w), C.byref(h)),
+                    "vo_debug_level")
+        return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def debug_candidates(self, image, level, cap=1 << 20):
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int()
+        self._check(self.lib.vo_debug_candidates(self.h, image, level, _p(out), cap, C.byref(n)),
+                    "vo_debug_candidates")
+        return out[: n.value].copy()
+
+    def hamming_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.full((len(q), 2), -7, np.int32)
+        dist = np.full((len(q), 2), -7, np.int32)
+        self._check(self.lib.vo_hamming_knn2(self.h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)),
+                    "vo_hamming_knn2")
+        return idx, dist
+
+    def match_ratio(self, q, t, ratio=0.75):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        n = max(len(q), 1)
+        qi, ti, d = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        m = C.c_int()
+        self._check(self.lib.vo_match_ratio(self.h, _p(q), len(q), _p(t), len(t), float(ratio), _p(qi), _p(ti),
+                                            _p(d), C.byref(m)), "vo_match_ratio")
+        return qi[: m.value].copy(), ti[: m.value].copy(), d[: m.value].copy()
+
+    def estimate_motion(self, p1, p2, K, threshold=1.0, confidence=0.999, fixed_iters=0):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        Kd = np.asarray(K, np.float64)
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        inl, valid = C.c_int(), C.c_int()
+        mask = np.zeros(max(n, 1), np.uint8)
+        self._check(self.lib.vo_estimate_motion(self.h, _p(p1), _p(p2), n, _p(Kd), threshold, confidence,
+                                                int(fixed_iters), _p(R), _p(t), C.byref(inl), C.byref(valid),
+                                                _p(mask)), "vo_estimate_motion")
+        return dict(valid=bool(valid.value), inliers=inl.value, R=R, t=t, mask=mask[:n])
+
+    def find_essential(self, p1, p2, K, threshold=1.0, confidence=0.999, fixed_iters=0):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        Kd = np.asarray(K, np.float64)
+        E = np.zeros((3, 3))
+        mask = np.zeros(max(n, 1), np.uint8)
+        good, iters = C.c_int(), C.c_int()
+        samples = np.full((max(1000, fixed_iters), 5), -1, np.int32)
+        self._check(self.lib.vo_find_essential(self.h, _p(p1), _p(p2), n, _p(Kd), threshold, confidence,
+                                               int(fixed_iters), _p(E), _p(mask), C.byref(good), C.byref(iters),
+                                               _p(samples)), "vo_find_essential")
+        return good.value, E, mask[:n], iters.value, samples[: iters.value]
+
+    # ---- device-resident entry points (pointers are integers / c_void_p) ---------
+    def orb_detect_batch_dev(self, d_imgs, n_images, rows, cols, step, image_stride, max_features, d_kps, d_desc,
+                             cap, d_counts):
+        self._check(self.lib.vo_orb_detect_batch_dev(self.h, d_imgs, n_images, rows, cols, step, image_stride,
+                                                     max_features, d_kps, d_desc, cap, d_counts),
+                    "vo_orb_detect_batch_dev")
+
+    def hamming_knn2_dev(self, d_q, nq, d_t, nt, d_idx2, d_dist2):
+        self._check(self.lib.vo_hamming_knn2_dev(self.h, d_q, nq, d_t, nt, d_idx2, d_dist2), "vo_hamming_knn2_dev")
+
+    def pipeline_pairs_dev(self, d_imgs, n_pairs, rows, cols, step, image_stride, max_features, ratio, K, threshold,
+                           confidence, fixed_iters, d_results):
+        Kd = np.asarray(K, np.float64)
+        self._check(self.lib.vo_pipeline_pairs_dev(self.h, d_imgs, n_pairs, rows, cols, step, image_stride,
+                                                   max_features, ratio, _p(Kd), threshold, confidence, fixed_iters,
+                                                   d_results), "vo_pipeline_pairs_dev")

@@ -1,0 +1,102 @@
+// Context management for libvo_hip.so: device selection, the stream every
+// kernel is enqueued on, grow-only device buffers and the last-error string.
+#include "vo_internal.h"
+
+namespace vo {
+
+int fail(vo_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+// Grow-only device buffer: reallocates (after draining the stream) only when
+// the request exceeds what is already there.
+int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes && b.p) return VO_OK;
+    if (bytes == 0) bytes = 256;
+    if (b.p) {
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        VO_HIP(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, VO_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.bytes = want;
+    return VO_OK;
+}
+
+}  // namespace vo
+
+using namespace vo;
+
+extern "C" int vo_ctx_create(int device, vo_ctx** out) {
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VO_ERR_HIP;
+    if (device < 0 || device >= n) return VO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return VO_ERR_HIP;
+    vo_ctx* c = new vo_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return VO_ERR_HIP;
+    }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return VO_ERR_HIP;
+        }
+    *out = c;
+    return VO_OK;
+}
+
+extern "C" void vo_ctx_destroy(vo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
+                      &c->kp_resp,  &c->kp_angle, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
+                      &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->m_top2,   &c->m_qidx,
+                      &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
+                      &c->r_models, &c->r_nmodels, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_res,
+                      &c->p_kps,    &c->p_desc,   &c->p_cnt};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* vo_last_error(const vo_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" void* vo_ctx_stream(vo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int vo_sync(vo_ctx* c) {
+    if (!c) return VO_ERR_INVALID;
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_set_timing(vo_ctx* c, int enabled) {
+    if (!c) return VO_ERR_INVALID;
+    c->timing = enabled != 0;
+    c->last_ms[0] = c->last_ms[1] = -1.f;
+    return VO_OK;
+}
+
+extern "C" float vo_last_kernel_ms(vo_ctx* c, int which) {
+    if (!c || which < 0 || which > 1 || !c->timing) return -1.f;
+    // events are recorded on the context's stream; wait for the later one
+    hipEvent_t a = c->ev[which * 2], b = c->ev[which * 2 + 1];
+    if (hipEventSynchronize(b) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
+    return ms;
+}

@@ -1,0 +1,106 @@
+// Internal declarations shared by the translation units of libvo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/vo_hip.h"
+
+namespace vo {
+
+constexpr int kLevels = 8;
+constexpr int kEdge = 31;        // ORB edgeThreshold
+constexpr int kHalfPatch = 15;   // patchSize / 2
+constexpr int kFastThr = 20;
+constexpr int kSelCap = 8192;    // largest per-level list the select kernel sorts in LDS
+
+// Per-level geometry of a batch of equally sized images.
+struct LevelGeom {
+    int w, h;
+    int pitch;           // bytes per row in the pyramid / blur blocks (level 0 of pyr: input step)
+    uint32_t off;        // byte offset of the level inside one image's pyramid / blur block
+    float scale;         // layerScale
+    int quota;           // nfeaturesPerLevel
+    int cand_off;        // offset (entries) of the level's candidate list inside one image's block
+    int cand_cap;
+    int kp_off;          // offset (entries) of the level's selected-keypoint list
+    int kp_cap;
+    int fast_tx, fast_ty, fast_tile0;   // FAST tile grid of the level and first flat tile id
+    int blur_tx, blur_ty, blur_tile0;
+    uint32_t xtab, ytab; // offsets into the resize coefficient table (levels >= 1)
+};
+
+struct Geom {
+    LevelGeom L[kLevels];
+    int rows, cols, step;
+    int n_images;
+    size_t in_stride;     // bytes between input images
+    size_t blk_stride;    // bytes of one image's pyramid (and blur) block
+    int cand_stride;      // candidate entries per image
+    int kp_stride;        // selected-keypoint entries per image
+    int fast_tiles, blur_tiles;
+    int max_features;
+    int sel_cap;          // LDS list capacity chosen for the select kernel
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace vo
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[2] = {-1.f, -1.f};
+
+    // detection workspace
+    vo::Geom g{};
+    bool geom_valid = false;
+    std::vector<uint32_t> h_tab;   // resize tables (host copy)
+    vo::DevBuf tab, pyr, blur, cand, cand_cnt, kp_x, kp_y, kp_resp, kp_angle, kp_cnt, flags;
+    const uint8_t* last_imgs = nullptr;
+    // staging for the host-buffer entry points
+    vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist;
+    // matching / RANSAC workspace
+    vo::DevBuf m_top2, m_qidx, m_tidx, m_dist, m_p1, m_p2, m_cnt;
+    vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_counts, r_best, r_mask, r_pts, r_res;
+    // pipeline workspace
+    vo::DevBuf p_kps, p_desc, p_cnt;
+};
+
+namespace vo {
+
+int fail(vo_ctx* c, int code, const std::string& msg);
+int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
+
+#define VO_HIP(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return vo::fail((c), VO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// orb
+int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in_stride, int max_features);
+int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
+// match
+int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
+                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2);
+int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
+                 int nq_max, int batch,
+                 float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
+                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch);
+// ransac
+int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
+               const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
+               double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
+               int samples_cap);
+
+}  // namespace vo

@@ -1,0 +1,296 @@
+// Brute-force Hamming 2-nearest-neighbour search and Lowe ratio test on
+// gfx950.  Stands in for cv::BFMatcher(NORM_HAMMING)::knnMatch(k=2) and the
+// ratio loop of ref:src/feature_matcher.cpp:26-39.
+//
+// Integer VALU work, no MFMA: each lane keeps QPL query descriptors (8 dwords
+// each) in registers; 256-row train tiles are staged in LDS by coalesced 32-B
+// row loads and read back as wave-wide broadcasts; distance = 8 x
+// (v_xor, v_bcnt accumulate); the running two best are kept as packed keys
+// (distance << 16 | train row) so that one v_min and one v_med3 update them
+// and ties resolve to the lower train row exactly as an ascending scan with a
+// strict '<' does.
+#include "vo_internal.h"
+
+namespace vo {
+
+constexpr int MT_ROWS = 256;   // train rows per LDS tile (8 KiB)
+
+// median of (a, b, c) given a <= b: the compiler folds this to one v_med3_u32
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) { return min(b, max(a, c)); }
+
+// Two smallest of {a0<=a1} U {b0<=b1} as 64-bit keys (distance << 32 | row).
+__device__ __forceinline__ void merge2(unsigned long long& a0, unsigned long long& a1, unsigned long long b0,
+                                       unsigned long long b1) {
+    unsigned long long lo = a0 < b0 ? a0 : b0;
+    unsigned long long hi = a0 < b0 ? b0 : a0;
+    unsigned long long s = a0 < b0 ? a1 : b1;   // second of the list that supplied lo
+    a0 = lo;
+    a1 = hi < s ? hi : s;
+}
+
+template <int QPL>
+__global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr,
+                                                   int cnt_stride, int nq_max, size_t q_stride, const uint8_t* __restrict__ t,
+                                                   const int32_t* __restrict__ nt_arr, int nt_max, size_t t_stride,
+                                                   int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[MT_ROWS * 8];
+    __shared__ unsigned long long part[4][64 * QPL][2];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
+    const int nt = nt_arr ? min(nt_arr[b * cnt_stride], nt_max) : nt_max;
+    const int qbase = blockIdx.x * 64 * QPL;
+    if (qbase >= nq) return;
+    const uint8_t* qb = q + (size_t)b * q_stride;
+    const uint8_t* tb = t + (size_t)b * t_stride;
+
+    uint32_t qr[QPL][8];
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) {
+        int qi = min(qbase + k * 64 + lane, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)qi * 32);
+        uint4 a = p[0], c = p[1];
+        qr[k][0] = a.x; qr[k][1] = a.y; qr[k][2] = a.z; qr[k][3] = a.w;
+        qr[k][4] = c.x; qr[k][5] = c.y; qr[k][6] = c.z; qr[k][7] = c.w;
+    }
+    unsigned long long best0[QPL], best1[QPL];
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) best0[k] = best1[k] = ~0ull;
+
+    for (int cbase = 0; cbase < nt; cbase += 65536) {
+        const int cn = min(nt - cbase, 65536);
+        uint32_t k0[QPL], k1[QPL];
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) k0[k] = k1[k] = 0xFFFFFFFFu;
+        for (int t0 = 0; t0 < cn; t0 += MT_ROWS) {
+            __syncthreads();
+            if (t0 + tid < cn) {
+                const uint4* p = reinterpret_cast<const uint4*>(tb + (size_t)(cbase + t0 + tid) * 32);
+                uint4 a = p[0], c = p[1];
+                uint4* d = reinterpret_cast<uint4*>(&tile[tid * 8]);
+                d[0] = a;
+                d[1] = c;
+            }
+            __syncthreads();
+            const int r0 = wave * 64;
+            const int rn = min(max(cn - t0 - r0, 0), 64);
+#pragma unroll 4
+            for (int r = 0; r < rn; ++r) {
+                const uint4* tp = reinterpret_cast<const uint4*>(&tile[(r0 + r) * 8]);
+                uint4 ta = tp[0], tc = tp[1];
+                const uint32_t j = (uint32_t)(t0 + r0 + r);
+#pragma unroll
+                for (int k = 0; k < QPL; ++k) {
+                    uint32_t d = __popc(qr[k][0] ^ ta.x);
+                    d += __popc(qr[k][1] ^ ta.y);
+                    d += __popc(qr[k][2] ^ ta.z);
+                    d += __popc(qr[k][3] ^ ta.w);
+                    d += __popc(qr[k][4] ^ tc.x);
+                    d += __popc(qr[k][5] ^ tc.y);
+                    d += __popc(qr[k][6] ^ tc.z);
+                    d += __popc(qr[k][7] ^ tc.w);
+                    uint32_t key = (d << 16) | j;
+                    k1[k] = med3u(k0[k], k1[k], key);
+                    k0[k] = min(k0[k], key);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) {
+            unsigned long long b0 = k0[k] == 0xFFFFFFFFu
+                                        ? ~0ull
+                                        : ((unsigned long long)(k0[k] >> 16) << 32) | (uint32_t)(cbase + (k0[k] & 0xFFFF));
+            unsigned long long b1 = k1[k] == 0xFFFFFFFFu
+                                        ? ~0ull
+                                        : ((unsigned long long)(k1[k] >> 16) << 32) | (uint32_t)(cbase + (k1[k] & 0xFFFF));
+            merge2(best0[k], best1[k], b0, b1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPL; ++k) {
+        part[wave][k * 64 + lane][0] = best0[k];
+        part[wave][k * 64 + lane][1] = best1[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * QPL; i += 256) {
+        int qi = qbase + i;
+        if (qi >= nq) continue;
+        unsigned long long a0 = part[0][i][0], a1 = part[0][i][1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) merge2(a0, a1, part[w][i][0], part[w][i][1]);
+        size_t o = ((size_t)b * nq_max + qi) * 2;
+        idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
+        idx2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(uint32_t)a1;
+        dist2[o] = a0 == ~0ull ? -1 : (int32_t)(a0 >> 32);
+        dist2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(a1 >> 32);
+    }
+}
+
+// Lowe ratio test and ordered compaction (query order), one workgroup per
+// pair.  Also gathers the matched keypoint coordinates.
+__global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ idx2, const int32_t* __restrict__ dist2,
+                                                    const int32_t* __restrict__ nq_arr, int cnt_stride, int nq_max,
+                                                    float ratio,
+                                                    const vo_keypoint* __restrict__ kp1,
+                                                    const vo_keypoint* __restrict__ kp2, size_t kp_stride,
+                                                    int32_t* __restrict__ qidx, int32_t* __restrict__ tidx,
+                                                    float* __restrict__ dist, float* __restrict__ p1,
+                                                    float* __restrict__ p2, int32_t* __restrict__ nmatch) {
+    __shared__ int wsum[4];
+    __shared__ int base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        int qi = q0 + tid;
+        bool keep = false;
+        int i0 = -1;
+        float d0 = 0.f;
+        if (qi < nq) {
+            size_t o = ((size_t)b * nq_max + qi) * 2;
+            i0 = idx2[o];
+            int i1 = idx2[o + 1];
+            if (i0 >= 0 && i1 >= 0) {
+                d0 = (float)dist2[o];
+                float d1 = (float)dist2[o + 1];
+                keep = d0 < ratio * d1;
+            }
+        }
+        unsigned long long m = __ballot(keep);
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            size_t o = (size_t)b * nq_max + off + before;
+            qidx[o] = qi;
+            tidx[o] = i0;
+            dist[o] = d0;
+            if (kp1 && kp2) {
+                const vo_keypoint& a = kp1[(size_t)b * kp_stride + qi];
+                const vo_keypoint& c = kp2[(size_t)b * kp_stride + i0];
+                p1[o * 2] = a.x;
+                p1[o * 2 + 1] = a.y;
+                p2[o * 2] = c.x;
+                p2[o * 2 + 1] = c.y;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) nmatch[b] = base;
+}
+
+int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
+                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
+    if (nq_max <= 0 || batch <= 0) return VO_OK;
+    // queries per lane: as many as keeps >= ~2048 workgroups' worth of waves in flight
+    int qpl = 4;
+    while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 1024) qpl >>= 1;
+    dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
+    hipStream_t s = c->stream;
+    if (c->timing) VO_HIP(c, hipEventRecord(c->ev[2], s));
+    if (qpl == 4)
+        hipLaunchKernelGGL(knn2_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
+                           t_stride, d_idx2, d_dist2);
+    else if (qpl == 2)
+        hipLaunchKernelGGL(knn2_kernel<2>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
+                           t_stride, d_idx2, d_dist2);
+    else
+        hipLaunchKernelGGL(knn2_kernel<1>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
+                           t_stride, d_idx2, d_dist2);
+    if (c->timing) VO_HIP(c, hipEventRecord(c->ev[3], s));
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
+                 int nq_max, int batch,
+                 float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
+                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch) {
+    if (batch <= 0) return VO_OK;
+    hipLaunchKernelGGL(ratio_kernel, dim3(batch), dim3(256), 0, c->stream, d_idx2, d_dist2, d_nq, cnt_stride, nq_max, ratio, d_kp1,
+                       d_kp2, kp_stride, d_qidx, d_tidx, d_dist, d_p1, d_p2, d_nmatch);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+}  // namespace vo
+
+using namespace vo;
+
+extern "C" int vo_hamming_knn2_dev(vo_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2,
+                                   int32_t* d_dist2) {
+    if (!c) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_idx2 || !d_dist2)) || (nt > 0 && !d_t))
+        return fail(c, VO_ERR_INVALID, "vo_hamming_knn2_dev: bad argument");
+    if (((uintptr_t)d_q | (uintptr_t)d_t) & 15)
+        return fail(c, VO_ERR_INVALID, "vo_hamming_knn2_dev: descriptor arrays must be 16-byte aligned");
+    VO_HIP(c, hipSetDevice(c->device));
+    return knn2_launch(c, d_q, nullptr, 1, nq, 0, d_t, nullptr, nt, 0, 1, d_idx2, d_dist2);
+}
+
+extern "C" int vo_hamming_knn2(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2,
+                               int32_t* dist2) {
+    if (!c) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx2 || !dist2)) || (nt > 0 && !t))
+        return fail(c, VO_ERR_INVALID, "vo_hamming_knn2: bad argument");
+    if (nq == 0) return VO_OK;
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->st_q, (size_t)nq * 32))) return rc;
+    if ((rc = ensure(c, c->st_t, (size_t)std::max(nt, 1) * 32))) return rc;
+    if ((rc = ensure(c, c->st_idx, (size_t)nq * 8))) return rc;
+    if ((rc = ensure(c, c->st_dist, (size_t)nq * 8))) return rc;
+    VO_HIP(c, hipMemcpyAsync(c->st_q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0) VO_HIP(c, hipMemcpyAsync(c->st_t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = knn2_launch(c, (const uint8_t*)c->st_q.p, nullptr, 1, nq, 0, (const uint8_t*)c->st_t.p, nullptr, nt, 0, 1,
+                          (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
+        return rc;
+    VO_HIP(c, hipMemcpyAsync(idx2, c->st_idx.p, (size_t)nq * 8, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(dist2, c->st_dist.p, (size_t)nq * 8, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_match_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
+                              int32_t* query_idx, int32_t* train_idx, float* distance, int* n_out) {
+    if (!c) return VO_ERR_INVALID;
+    if (!n_out) return fail(c, VO_ERR_INVALID, "vo_match_ratio: n_out is NULL");
+    *n_out = 0;
+    if (nq <= 0 || nt <= 0 || !q || !t) return VO_OK;   // empty descriptors -> empty result
+    if (!query_idx || !train_idx || !distance) return fail(c, VO_ERR_INVALID, "vo_match_ratio: NULL output");
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->st_q, (size_t)nq * 32))) return rc;
+    if ((rc = ensure(c, c->st_t, (size_t)nt * 32))) return rc;
+    if ((rc = ensure(c, c->st_idx, (size_t)nq * 8))) return rc;
+    if ((rc = ensure(c, c->st_dist, (size_t)nq * 8))) return rc;
+    if ((rc = ensure(c, c->m_qidx, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(c, c->m_tidx, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(c, c->m_dist, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(c, c->m_cnt, 64))) return rc;
+    VO_HIP(c, hipMemcpyAsync(c->st_q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->st_t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = knn2_launch(c, (const uint8_t*)c->st_q.p, nullptr, 1, nq, 0, (const uint8_t*)c->st_t.p, nullptr, nt, 0, 1,
+                          (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
+        return rc;
+    if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, nullptr, 1, nq, 1, ratio, nullptr,
+                           nullptr, 0, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p, (float*)c->m_dist.p, nullptr,
+                           nullptr, (int32_t*)c->m_cnt.p)))
+        return rc;
+    int32_t m = 0;
+    VO_HIP(c, hipMemcpyAsync(&m, c->m_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    if (m > 0) {
+        VO_HIP(c, hipMemcpyAsync(query_idx, c->m_qidx.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpyAsync(train_idx, c->m_tidx.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpyAsync(distance, c->m_dist.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *n_out = m;
+    return VO_OK;
+}

@@ -1,0 +1,63 @@
+// Fused frame-pair pipeline: detect x2 -> kNN(2) + ratio -> E-RANSAC + pose,
+// every intermediate resident in HBM.  Stands in for match_images_orb
+// (ref:src/image_matcher.cpp:71-81) followed by estimate_motion as the
+// reference's main loop chains them (ref:src/main.cpp:162-170).
+#include "vo_internal.h"
+
+namespace vo {
+
+__global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32_t* __restrict__ kp_cnt,
+                                   const int32_t* __restrict__ nmatch, int n_pairs) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    res[p].n_kp1 = kp_cnt[2 * p];
+    res[p].n_kp2 = kp_cnt[2 * p + 1];
+    res[p].n_matches = nmatch[p];
+}
+
+}  // namespace vo
+
+using namespace vo;
+
+extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
+                                     size_t image_stride, int max_features, float ratio, const double K[4],
+                                     double threshold, double confidence, int fixed_iters,
+                                     vo_pair_result* d_results) {
+    if (!c) return VO_ERR_INVALID;
+    if (n_pairs <= 0 || rows <= 0 || cols <= 0 || step < cols || max_features <= 0 || !d_imgs || !K || !d_results)
+        return fail(c, VO_ERR_INVALID, "vo_pipeline_pairs_dev: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    int n_images = 2 * n_pairs, rc;
+    if ((rc = orb_prepare(c, n_images, rows, cols, step, image_stride, max_features))) return rc;
+    const int cap = c->g.kp_stride;   // quota + slack of every level: the detector cannot return more
+    if ((rc = ensure(c, c->p_kps, (size_t)n_images * cap * sizeof(vo_keypoint)))) return rc;
+    if ((rc = ensure(c, c->p_desc, (size_t)n_images * cap * 32))) return rc;
+    if ((rc = ensure(c, c->p_cnt, (size_t)n_images * 4))) return rc;
+    if ((rc = ensure(c, c->st_idx, (size_t)n_pairs * cap * 8))) return rc;
+    if ((rc = ensure(c, c->st_dist, (size_t)n_pairs * cap * 8))) return rc;
+    if ((rc = ensure(c, c->m_qidx, (size_t)n_pairs * cap * 4))) return rc;
+    if ((rc = ensure(c, c->m_tidx, (size_t)n_pairs * cap * 4))) return rc;
+    if ((rc = ensure(c, c->m_dist, (size_t)n_pairs * cap * 4))) return rc;
+    if ((rc = ensure(c, c->m_p1, (size_t)n_pairs * cap * 8))) return rc;
+    if ((rc = ensure(c, c->m_p2, (size_t)n_pairs * cap * 8))) return rc;
+    if ((rc = ensure(c, c->m_cnt, (size_t)n_pairs * 4))) return rc;
+    vo_keypoint* kps = (vo_keypoint*)c->p_kps.p;
+    uint8_t* desc = (uint8_t*)c->p_desc.p;
+    int32_t* cnt = (int32_t*)c->p_cnt.p;
+    if ((rc = orb_run(c, d_imgs, kps, desc, cap, cnt))) return rc;
+    if ((rc = knn2_launch(c, desc, cnt, 2, cap, (size_t)2 * cap * 32, desc + (size_t)cap * 32, cnt + 1, cap,
+                          (size_t)2 * cap * 32, n_pairs, (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
+        return rc;
+    if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, cnt, 2, cap, n_pairs, ratio,
+                           kps, kps + cap, (size_t)2 * cap, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p,
+                           (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p)))
+        return rc;
+    if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, (const int32_t*)c->m_cnt.p, cap, n_pairs,
+                         K, threshold, confidence, fixed_iters, d_results, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         0)))
+        return rc;
+    hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, d_results, cnt,
+                       (const int32_t*)c->m_cnt.p, n_pairs);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}

@@ -1,0 +1,938 @@
+// Essential-matrix RANSAC and pose recovery on gfx950.  Stands in for
+// cv::findEssentialMat(RANSAC) + cv::recoverPose as called by
+// ref:src/motion_estimator.cpp:69-85.
+//
+// Hypotheses are generated in rounds: the index sets come from the same
+// multiply-with-carry stream cv::RNG(-1) produces, a round of 5-point solves
+// runs one hypothesis per lane (fp64, 10x20 elimination matrix in LDS), every
+// (hypothesis, model) is scored by a wavefront over the points (Sampson error,
+// ballot-free per-lane counts reduced across the wave), and one lane per pair
+// then replays the sequential RANSAC bookkeeping (strictly-greater best model,
+// adaptive iteration count) over the round's counts, so the winner is the one
+// the serial loop would have picked.
+#include <cfloat>
+#include <cmath>
+
+#include "vo_internal.h"
+
+namespace vo {
+
+constexpr int kMaxModels = 10;
+constexpr int kMaxIters = 1000;
+
+struct RState {
+    unsigned long long rng;
+    int n;
+    int niters;
+    int iters_run;
+    int max_good;
+    int done;
+    int exact5;
+    double bestE[9];
+};
+
+struct RParams {
+    double ifx, ify, bx, by;   // normalisation x*ifx + bx
+    double fx_mean;
+    double threshold;          // already divided by (fx+fy)/2
+    float t2;                  // (float)(threshold^2)
+    double confidence;
+    int fixed_iters;
+};
+
+// ------------------------------------------------------------------ points
+__global__ void normalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                 const int32_t* __restrict__ n_arr, int n_max, RParams P, double* __restrict__ m) {
+    int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = n_arr ? min(n_arr[b], n_max) : n_max;
+    if (i >= n) return;
+    size_t o = (size_t)b * n_max + i;
+    double x1 = (double)p1[o * 2] * P.ifx + P.bx, y1 = (double)p1[o * 2 + 1] * P.ify + P.by;
+    double x2 = (double)p2[o * 2] * P.ifx + P.bx, y2 = (double)p2[o * 2 + 1] * P.ify + P.by;
+    double* d = m + o * 4;
+    d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
+}
+
+__device__ __forceinline__ uint32_t rng_next(unsigned long long& s) {
+    s = (unsigned long long)(uint32_t)s * 4164903690u + (uint32_t)(s >> 32);
+    return (uint32_t)s;
+}
+
+// Draws `count` 5-subsets (distinct indices, rejection as in getSubset).
+__device__ void draw_samples(RState& st, int32_t* out, int count) {
+    unsigned long long s = st.rng;
+    uint32_t n = (uint32_t)st.n;
+    for (int h = 0; h < count; ++h) {
+        int idx[5];
+        for (int i = 0; i < 5; ++i) {
+            int v;
+            bool dup;
+            do {
+                v = (int)(rng_next(s) % n);
+                dup = false;
+                for (int k = 0; k < i; ++k) dup |= idx[k] == v;
+            } while (dup);
+            idx[i] = v;
+            out[h * 5 + i] = v;
+        }
+    }
+    st.rng = s;
+}
+
+__device__ int update_num_iters(double p, double ep, int max_iters) {
+    p = fmin(fmax(p, 0.), 1.);
+    ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, 5.0);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : __double2int_rn(num / denom);
+}
+
+__global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__ n_arr, int n_max, int batch,
+                            RParams P, int32_t* __restrict__ samples, int samples_stride, int first_round) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    RState s;
+    s.rng = ~0ull;
+    s.n = n_arr ? min(n_arr[b], n_max) : n_max;
+    s.niters = P.fixed_iters > 0 ? P.fixed_iters : kMaxIters;
+    s.iters_run = 0;
+    s.max_good = 0;
+    s.done = s.n < 5;
+    s.exact5 = s.n == 5;
+    for (int k = 0; k < 9; ++k) s.bestE[k] = 0;
+    int32_t* out = samples + (size_t)b * samples_stride;
+    if (s.exact5) {
+        s.niters = 1;
+        for (int i = 0; i < 5; ++i) out[i] = i;
+    } else if (!s.done) {
+        draw_samples(s, out, min(first_round, s.niters));
+    }
+    st[b] = s;
+}
+
+// ------------------------------------------------------------------ five-point solver
+constexpr int ST = 64;   // lanes per solve workgroup (one hypothesis each)
+
+// quad[10] (+)= s * a[4] (x) b[4]
+__device__ __forceinline__ void mul_ll(const double* a, const double* b, double s, double* q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            constexpr int QI[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+            q[QI[i][j]] += s * (a[i] * b[j]);
+        }
+}
+
+// row of A (LDS, stride ST doubles) += s * q[10] (x) l[4]
+__device__ __forceinline__ void mul_ql_row(const double* q, const double* l, double s, double* row) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            constexpr int CI[10][4] = {{0, 2, 4, 5},    {2, 3, 8, 9},     {4, 8, 10, 11},   {5, 9, 11, 12},
+                                       {3, 1, 6, 7},    {8, 6, 13, 14},   {9, 7, 14, 15},   {10, 13, 16, 17},
+                                       {11, 14, 17, 18}, {12, 15, 18, 19}};
+            row[CI[i][j] * ST] += s * (q[i] * l[j]);
+        }
+}
+
+// j-th derivative of the polynomial c (degree n) at x; dc[j] holds its coefficients.
+__device__ __forceinline__ double poly_eval(const double* d, int deg, double x) {
+    double v = d[deg];
+    for (int i = deg - 1; i >= 0; --i) v = v * x + d[i];
+    return v;
+}
+
+// Real roots (ascending) of c[0..10] by derivative interlacing: the roots of
+// each derivative bracket the monotone pieces of the next lower one, and
+// every bracket with a sign change is closed by a Newton/bisection hybrid.
+__device__ int real_roots(const double* c, double* roots) {
+    double cmax = 0;
+    for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(c[i]));
+    if (!(cmax > 0) || !isfinite(cmax)) return 0;
+    int n = 10;
+    while (n > 0 && fabs(c[n]) <= 1e-14 * cmax) --n;
+    if (n == 0) return 0;
+    double dc[11][11];   // dc[j] = coefficients of the j-th derivative
+    for (int i = 0; i <= n; ++i) dc[0][i] = c[i];
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i <= n - j; ++i) dc[j][i] = dc[j - 1][i + 1] * (double)(i + 1);
+    double prev[10], cur[10];
+    int np = 0;
+    {
+        const double* d = dc[n - 1];   // linear
+        prev[0] = -d[0] / d[1];
+        np = 1;
+    }
+    for (int j = n - 2; j >= 0; --j) {
+        const double* d = dc[j];
+        const double* dd = dc[j + 1];
+        int deg = n - j;
+        double R = 0;
+        for (int i = 0; i < deg; ++i) R = fmax(R, fabs(d[i] / d[deg]));
+        R += 1.0;
+        int nc = 0;
+        double a = -R, fa = poly_eval(d, deg, a);
+        for (int k = 0; k <= np; ++k) {
+            double b = k < np ? fmin(fmax(prev[k], -R), R) : R;
+            double fb = poly_eval(d, deg, b);
+            if (b > a) {
+                if (fa == 0.0) {
+                    if (nc == 0 || cur[nc - 1] != a) cur[nc++] = a;
+                } else if ((fa < 0) != (fb < 0) && fb != 0.0) {
+                    // bracketed root: safeguarded Newton (Numerical-Recipes style rtsafe)
+                    double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
+                    double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold;
+                    double f = poly_eval(d, deg, x), df = poly_eval(dd, deg - 1, x);
+                    for (int it = 0; it < 100; ++it) {
+                        if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+                            dxold = dx;
+                            dx = 0.5 * (xh - xl);
+                            x = xl + dx;
+                        } else {
+                            dxold = dx;
+                            dx = f / df;
+                            x -= dx;
+                        }
+                        if (fabs(dx) <= 4.0 * DBL_EPSILON * fmax(1.0, fabs(x))) break;
+                        f = poly_eval(d, deg, x);
+                        df = poly_eval(dd, deg - 1, x);
+                        if (f == 0.0) break;
+                        if (f < 0.0) xl = x; else xh = x;
+                    }
+                    if (nc < 10) cur[nc++] = x;
+                }
+            }
+            if (b > a) {
+                a = b;
+                fa = fb;
+            }
+        }
+        if (fa == 0.0 && nc < 10 && (nc == 0 || cur[nc - 1] != a)) cur[nc++] = a;
+        np = nc;
+        for (int k = 0; k < nc; ++k) prev[k] = cur[k];
+    }
+    for (int k = 0; k < np; ++k) roots[k] = prev[k];
+    return np;
+}
+
+// x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm
+// essential matrices (row-major) to Es.  sA: this lane's column of the
+// 10x20 elimination matrix in LDS (element (r,c) at sA[(r*20+c)*ST]).
+__device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
+    // ---- null space of the 5x9 epipolar constraint matrix (Householder QR of its transpose)
+    double M[9][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        double a = x1[j * 2], b = x1[j * 2 + 1], c = x2[j * 2], d = x2[j * 2 + 1];
+        M[0][j] = a * c; M[1][j] = b * c; M[2][j] = c;
+        M[3][j] = a * d; M[4][j] = b * d; M[5][j] = d;
+        M[6][j] = a; M[7][j] = b; M[8][j] = 1.0;
+    }
+    double beta[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double s = 0;
+#pragma unroll
+        for (int i = k; i < 9; ++i) s += M[i][k] * M[i][k];
+        double nrm = sqrt(s);
+        double alpha = M[k][k] > 0 ? -nrm : nrm;
+        double v0 = M[k][k] - alpha;
+        double vn = s - M[k][k] * M[k][k] + v0 * v0;
+        M[k][k] = v0;
+        beta[k] = vn > 0 ? 2.0 / vn : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < 5; ++j) {
+            double dot = 0;
+#pragma unroll
+            for (int i = k; i < 9; ++i) dot += M[i][k] * M[i][j];
+            dot *= beta[k];
+#pragma unroll
+            for (int i = k; i < 9; ++i) M[i][j] -= dot * M[i][k];
+        }
+    }
+    double EE[4][9];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        double e[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) e[i] = (i == 5 + t) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
+            double dot = 0;
+#pragma unroll
+            for (int i = k; i < 9; ++i) dot += M[i][k] * e[i];
+            dot *= beta[k];
+#pragma unroll
+            for (int i = k; i < 9; ++i) e[i] -= dot * M[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) EE[t][i] = e[i];
+    }
+    // ---- ten cubic constraints in (x,y,z) on E = x*EE0 + y*EE1 + z*EE2 + EE3
+    double El[9][4];
+#pragma unroll
+    for (int rc = 0; rc < 9; ++rc)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) El[rc][t] = EE[t][rc];
+#pragma unroll 1
+    for (int i = 0; i < 200; ++i) sA[i * ST] = 0.0;
+    {
+        // det(E) = 0
+        double m0[10] = {0}, m1[10] = {0}, m2[10] = {0};
+        mul_ll(El[4], El[8], 1.0, m0); mul_ll(El[5], El[7], -1.0, m0);
+        mul_ll(El[3], El[8], 1.0, m1); mul_ll(El[5], El[6], -1.0, m1);
+        mul_ll(El[3], El[7], 1.0, m2); mul_ll(El[4], El[6], -1.0, m2);
+        mul_ql_row(m0, El[0], 1.0, sA);
+        mul_ql_row(m1, El[1], -1.0, sA);
+        mul_ql_row(m2, El[2], 1.0, sA);
+    }
+    {
+        // (E E^T - trace(E E^T)/2 I) E = 0
+        double L[6][10];   // symmetric: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        const int sr[6] = {0, 0, 0, 1, 1, 2}, sc[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) L[s][i] = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mul_ll(El[sr[s] * 3 + k], El[sc[s] * 3 + k], 1.0, L[s]);
+        }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double tr = 0.5 * (L[0][i] + L[3][i] + L[5][i]);
+            L[0][i] -= tr; L[3][i] -= tr; L[5][i] -= tr;
+        }
+        const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double* row = sA + (size_t)(1 + r * 3 + c) * 20 * ST;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mul_ql_row(L[sym[r][k]], El[k * 3 + c], 1.0, row);
+            }
+    }
+    // ---- Gauss-Jordan on the first ten columns (partial pivoting)
+#define A_(r, c) sA[((r) * 20 + (c)) * ST]
+    for (int k = 0; k < 10; ++k) {
+        int p = k;
+        double best = fabs(A_(k, k));
+        for (int r = k + 1; r < 10; ++r) {
+            double v = fabs(A_(r, k));
+            if (v > best) { best = v; p = r; }
+        }
+        if (!(best > 1e-300)) return 0;
+        if (p != k)
+            for (int c = k; c < 20; ++c) {
+                double t = A_(k, c);
+                A_(k, c) = A_(p, c);
+                A_(p, c) = t;
+            }
+        double inv = 1.0 / A_(k, k);
+        for (int c = k; c < 20; ++c) A_(k, c) *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == k) continue;
+            double f = A_(r, k);
+            if (f == 0.0) continue;
+            for (int c = k; c < 20; ++c) A_(r, c) -= f * A_(k, c);
+        }
+    }
+    // rows 4..9 <-> x^2 z, x^2, y^2 z, y^2, x y z, x y; columns 10..19 <->
+    // x z^2, x z, x, y z^2, y z, y, z^3, z^2, z, 1.
+    // z*row(m) - row(m z):  x*p3(z) + y*q3(z) + r4(z) = 0, stored descending.
+    double bm[3][13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) bm[i][k] = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bm[i][k] += A_(5 + 2 * i, 10 + k);
+            bm[i][4 + k] += A_(5 + 2 * i, 13 + k);
+            bm[i][1 + k] -= A_(4 + 2 * i, 10 + k);
+            bm[i][5 + k] -= A_(4 + 2 * i, 13 + k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bm[i][8 + k] += A_(5 + 2 * i, 16 + k);
+            bm[i][9 + k] -= A_(4 + 2 * i, 16 + k);
+        }
+    }
+#undef A_
+    // ---- determinant polynomial (degree 10, ascending coefficients)
+    double cf[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) cf[i] = 0;
+    {
+        // ascending views: column 0/1 cubic, column 2 quartic
+        double f[3][3][5];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f[r][0][k] = bm[r][3 - k];
+                f[r][1][k] = bm[r][7 - k];
+            }
+            f[r][0][4] = f[r][1][4] = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) f[r][2][k] = bm[r][12 - k];
+        }
+        const int perm[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+        const double sgn[6] = {1, 1, 1, -1, -1, -1};
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            double t01[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t01[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) t01[i + j] += f[0][perm[p][0]][i] * f[1][perm[p][1]][j];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (i + j <= 10) cf[i + j] += sgn[p] * (t01[i] * f[2][perm[p][2]][j]);
+        }
+    }
+    double roots[10];
+    int nr = real_roots(cf, roots);
+    int count = 0;
+    for (int ri = 0; ri < nr && count < kMaxModels; ++ri) {
+        double z1 = roots[ri], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bz[j][0] = bm[j][0] * z3 + bm[j][1] * z2 + bm[j][2] * z1 + bm[j][3];
+            bz[j][1] = bm[j][4] * z3 + bm[j][5] * z2 + bm[j][6] * z1 + bm[j][7];
+            bz[j][2] = bm[j][8] * z4 + bm[j][9] * z3 + bm[j][10] * z2 + bm[j][11] * z1 + bm[j][12];
+        }
+        // null vector of the (numerically singular) 3x3: best-conditioned row cross product
+        double bx = 0, by = 0, bw = 0, bn = -1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int r0 = a == 2 ? 1 : 0, r1 = a == 0 ? 1 : 2;
+            double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
+            double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
+            double cw = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
+            double nn = cx * cx + cy * cy + cw * cw;
+            if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
+        }
+        if (!(bn > 0)) continue;
+        double inv = 1.0 / sqrt(bn);
+        bx *= inv; by *= inv; bw *= inv;
+        if (fabs(bw) < 1e-10) continue;
+        double x = bx / bw, y = by / bw;
+        double Ev[9], nrm = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            Ev[k] = EE[0][k] * x + EE[1][k] * y + EE[2][k] * z1 + EE[3][k];
+            nrm += Ev[k] * Ev[k];
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0) || !isfinite(nrm)) continue;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k] / nrm;
+        ++count;
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(ST) void solve_kernel(const RState* __restrict__ st, const double* __restrict__ m,
+                                                   int n_max, const int32_t* __restrict__ samples, int samples_stride,
+                                                   int h0, int hr, double* __restrict__ models,
+                                                   int32_t* __restrict__ nmodels) {
+    __shared__ double sA[200 * ST];
+    int b = blockIdx.y, h = blockIdx.x * ST + threadIdx.x;
+    const RState& s = st[b];
+    bool active = h < hr && !s.done && (h0 + h) < s.niters;
+    int nm = 0;
+    if (active) {
+        const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
+        double x1[10], x2[10];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double* p = m + ((size_t)b * n_max + idx[i]) * 4;
+            x1[i * 2] = p[0]; x1[i * 2 + 1] = p[1];
+            x2[i * 2] = p[2]; x2[i * 2 + 1] = p[3];
+        }
+        nm = five_point_dev(x1, x2, models + ((size_t)b * hr + h) * kMaxModels * 9, sA + threadIdx.x);
+    }
+    if (h < hr) nmodels[(size_t)b * hr + h] = nm;
+}
+
+// Sampson error of EMEstimatorCallback::computeError, cast to float.
+__device__ __forceinline__ float sampson_dev(const double* E, double x1, double y1, double x2, double y2) {
+    double Ex0 = E[0] * x1 + E[1] * y1 + E[2];
+    double Ex1 = E[3] * x1 + E[4] * y1 + E[5];
+    double Ex2 = E[6] * x1 + E[7] * y1 + E[8];
+    double Et0 = E[0] * x2 + E[3] * y2 + E[6];
+    double Et1 = E[1] * x2 + E[4] * y2 + E[7];
+    double x2tEx1 = x2 * Ex0 + y2 * Ex1 + Ex2;
+    double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+}
+
+// One wavefront per hypothesis: every lane walks the points with stride 64,
+// evaluates all of the hypothesis' models on each, and the per-lane inlier
+// counts are summed across the wave.
+__global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ st, const double* __restrict__ m,
+                                                    int n_max, int hr, const double* __restrict__ models,
+                                                    const int32_t* __restrict__ nmodels, float t2,
+                                                    int32_t* __restrict__ counts) {
+    __shared__ double sE[4][kMaxModels * 9];
+    int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int h = blockIdx.x * 4 + wave;
+    int nm = h < hr ? nmodels[(size_t)b * hr + h] : 0;   // wave-uniform
+    const double* Eg = models + ((size_t)b * hr + h) * kMaxModels * 9;
+    for (int i = lane; i < nm * 9; i += 64) sE[wave][i] = Eg[i];
+    __syncthreads();
+    if (nm == 0) return;
+    int n = st[b].n;
+    int cnt[kMaxModels];
+#pragma unroll
+    for (int k = 0; k < kMaxModels; ++k) cnt[k] = 0;
+    const double* pb = m + (size_t)b * n_max * 4;
+    for (int i = lane; i < n; i += 64) {
+        const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)i * 4);
+#pragma unroll
+        for (int k = 0; k < kMaxModels; ++k)
+            if (k < nm) cnt[k] += sampson_dev(&sE[wave][k * 9], p.x, p.y, p.z, p.w) <= t2;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxModels; ++k) {
+        if (k >= nm) break;
+        int v = cnt[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) counts[((size_t)b * hr + h) * kMaxModels + k] = v;
+    }
+}
+
+// Sequential RANSAC bookkeeping over one round, then the next round's samples.
+__global__ void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
+                              const double* __restrict__ models, const int32_t* __restrict__ nmodels,
+                              const int32_t* __restrict__ counts, int32_t* __restrict__ samples, int samples_stride,
+                              int next_round, int32_t* __restrict__ samples_log, int log_cap) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    RState s = stv[b];
+    if (s.done) return;
+    if (samples_log) {
+        const int32_t* src = samples + (size_t)b * samples_stride;
+        for (int h = 0; h < hr && h0 + h < s.niters && h0 + h < log_cap; ++h)
+            for (int i = 0; i < 5; ++i) samples_log[((size_t)b * log_cap + h0 + h) * 5 + i] = src[h * 5 + i];
+    }
+    int h = 0;
+    for (; h < hr; ++h) {
+        if (h0 + h >= s.niters) break;
+        int nm = nmodels[(size_t)b * hr + h];
+        if (s.exact5 && nm != 1) nm = 0;
+        for (int k = 0; k < nm; ++k) {
+            int good = counts[((size_t)b * hr + h) * kMaxModels + k];
+            if (good > max(s.max_good, 4)) {
+                s.max_good = good;
+                const double* E = models + (((size_t)b * hr + h) * kMaxModels + k) * 9;
+                for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
+                if (P.fixed_iters <= 0 && !s.exact5)
+                    s.niters = update_num_iters(P.confidence, (double)(s.n - good) / s.n, s.niters);
+            }
+        }
+        s.iters_run = h0 + h + 1;
+    }
+    if (h < hr || h0 + hr >= s.niters) {
+        s.done = 1;
+    } else if (next_round > 0) {
+        draw_samples(s, samples + (size_t)b * samples_stride, min(next_round, s.niters - (h0 + hr)));
+    } else {
+        s.done = 1;
+    }
+    stv[b] = s;
+}
+
+// ------------------------------------------------------------------ pose recovery
+// Smallest-eigenvalue eigenvector of a symmetric 4x4 (cyclic Jacobi).
+__device__ void smallest_eigvec4(double S[4][4], double* v) {
+    double V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double offd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) offd += S[i][j] * S[i][j];
+        double diag = S[0][0] * S[0][0] + S[1][1] * S[1][1] + S[2][2] * S[2][2] + S[3][3] * S[3][3];
+        if (offd <= 1e-60 * diag || offd == 0) break;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double apq = S[p][q];
+                if (apq == 0.0) continue;
+                double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double skp = S[k][p], skq = S[k][q];
+                    S[k][p] = c * skp - s * skq;
+                    S[k][q] = s * skp + c * skq;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double spk = S[p][k], sqk = S[q][k];
+                    S[p][k] = c * spk - s * sqk;
+                    S[q][k] = s * spk + c * sqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int best = 0;
+    double bv = S[0][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (S[i][i] < bv) { bv = S[i][i]; best = i; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
+}
+
+// decomposeEssentialMat: E = U diag(s,s,0) V^T -> R1 = U W V^T, R2 = U W^T V^T, t = u3.
+__device__ void decompose_essential_dev(const double* E, double* R1, double* R2, double* t) {
+    // eigen-decomposition of E^T E (3x3) by Jacobi -> V
+    double S[3][3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            S[i][j] = E[0 * 3 + i] * E[0 * 3 + j] + E[1 * 3 + i] * E[1 * 3 + j] + E[2 * 3 + i] * E[2 * 3 + j];
+            V[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double offd = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+        if (offd == 0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = S[p][q];
+                if (apq == 0.0) continue;
+                double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
+                double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 3; ++k) {
+                    double skp = S[k][p], skq = S[k][q];
+                    S[k][p] = c * skp - s * skq;
+                    S[k][q] = s * skp + c * skq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double spk = S[p][k], sqk = S[q][k];
+                    S[p][k] = c * spk - s * sqk;
+                    S[q][k] = s * spk + c * sqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    // order eigenvalues descending
+    int o0 = 0, o1 = 1, o2 = 2;
+    double e0 = S[0][0], e1 = S[1][1], e2 = S[2][2];
+    if (e1 > e0) { double tt = e0; e0 = e1; e1 = tt; int ti = o0; o0 = o1; o1 = ti; }
+    if (e2 > e0) { double tt = e0; e0 = e2; e2 = tt; int ti = o0; o0 = o2; o2 = ti; }
+    if (e2 > e1) { double tt = e1; e1 = e2; e2 = tt; int ti = o1; o1 = o2; o2 = ti; }
+    double v1[3], v2[3], v3[3], u1[3], u2[3], u3[3];
+    for (int k = 0; k < 3; ++k) { v1[k] = V[k][o0]; v2[k] = V[k][o1]; }
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    double n1 = 0, n2 = 0;
+    for (int i = 0; i < 3; ++i) {
+        u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
+        u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
+        n1 += u1[i] * u1[i];
+        n2 += u2[i] * u2[i];
+    }
+    n1 = 1.0 / sqrt(n1);
+    for (int i = 0; i < 3; ++i) u1[i] *= n1;
+    // re-orthogonalise u2 against u1 (repeated singular value)
+    double d12 = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]);
+    n2 = 0;
+    for (int i = 0; i < 3; ++i) { u2[i] -= d12 * u1[i]; n2 += u2[i] * u2[i]; }
+    n2 = 1.0 / sqrt(n2);
+    for (int i = 0; i < 3; ++i) u2[i] *= n2;
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    // U = [u1 u2 u3], V = [v1 v2 v3] both with det +1.
+    // U W V^T  = u1 (-v2)^T... expand: W = [0 1 0; -1 0 0; 0 0 1]
+    // (U W)   = [-u2, u1, u3];  (U W^T) = [u2, -u1, u3]
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            R1[i * 3 + j] = -u2[i] * v1[j] + u1[i] * v2[j] + u3[i] * v3[j];
+            R2[i * 3 + j] = u2[i] * v1[j] - u1[i] * v2[j] + u3[i] * v3[j];
+        }
+    t[0] = u3[0]; t[1] = u3[1]; t[2] = u3[2];
+}
+
+// One workgroup per pair: inlier mask of the winning E, four-fold
+// triangulation/cheirality test, pose selection and validity rules.
+__global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ stv, const double* __restrict__ m,
+                                                     int n_max, RParams P, vo_pair_result* __restrict__ res,
+                                                     double* __restrict__ E_out, uint8_t* __restrict__ mask_e,
+                                                     uint8_t* __restrict__ mask_pose, int32_t* __restrict__ good_out) {
+    __shared__ double sR[2][9], sT[3], sE[9];
+    __shared__ int cnt[4], sel;
+    int b = blockIdx.x, tid = threadIdx.x;
+    const RState& s = stv[b];
+    int n = s.n;
+    vo_pair_result* r = res ? res + b : nullptr;
+    if (tid < 4) cnt[tid] = 0;
+    if (tid < 9) sE[tid] = s.bestE[tid];
+    if (tid == 0) {
+        if (good_out) good_out[b * 2] = s.max_good;
+        if (good_out) good_out[b * 2 + 1] = s.iters_run;
+        if (E_out) for (int k = 0; k < 9; ++k) E_out[b * 9 + k] = s.max_good > 0 ? s.bestE[k] : 0.0;
+        if (r) {
+            r->inliers = 0;
+            r->valid = 0;
+            r->ransac_iters = s.iters_run;
+            for (int k = 0; k < 9; ++k) r->R[k] = 0;
+            for (int k = 0; k < 3; ++k) r->t[k] = 0;
+        }
+    }
+    if (s.max_good <= 0) {   // block-uniform
+        if (mask_e) for (int i = tid; i < n; i += 256) mask_e[(size_t)b * n_max + i] = 0;
+        if (mask_pose) for (int i = tid; i < n; i += 256) mask_pose[(size_t)b * n_max + i] = 0;
+        return;
+    }
+    if (tid == 0) decompose_essential_dev(s.bestE, sR[0], sR[1], sT);
+    __syncthreads();
+    const double* pb = m + (size_t)b * n_max * 4;
+    int my[4] = {0, 0, 0, 0};
+    unsigned char* scratch_mask = mask_pose ? mask_pose + (size_t)b * n_max : nullptr;
+    for (int i = tid; i < n; i += 256) {
+        double x1 = pb[i * 4], y1 = pb[i * 4 + 1], x2 = pb[i * 4 + 2], y2 = pb[i * 4 + 3];
+        bool inl = s.exact5 ? true : (sampson_dev(sE, x1, y1, x2, y2) <= P.t2);
+        if (mask_e) mask_e[(size_t)b * n_max + i] = inl;
+        unsigned bits = 0;
+        for (int c = 0; c < 4; ++c) {
+            const double* R = sR[c & 1];
+            double sg = c < 2 ? 1.0 : -1.0;
+            double Pm[3][4];
+            for (int a = 0; a < 3; ++a) {
+                Pm[a][0] = R[a * 3]; Pm[a][1] = R[a * 3 + 1]; Pm[a][2] = R[a * 3 + 2];
+                Pm[a][3] = sg * sT[a];
+            }
+            // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for P0 = [I|0] and P
+            double A[4][4];
+            A[0][0] = -1; A[0][1] = 0; A[0][2] = x1; A[0][3] = 0;
+            A[1][0] = 0; A[1][1] = -1; A[1][2] = y1; A[1][3] = 0;
+            for (int k = 0; k < 4; ++k) {
+                A[2][k] = x2 * Pm[2][k] - Pm[0][k];
+                A[3][k] = y2 * Pm[2][k] - Pm[1][k];
+            }
+            double S[4][4];
+            for (int a = 0; a < 4; ++a)
+                for (int k = 0; k < 4; ++k)
+                    S[a][k] = A[0][a] * A[0][k] + A[1][a] * A[1][k] + A[2][a] * A[2][k] + A[3][a] * A[3][k];
+            double X[4];
+            smallest_eigvec4(S, X);
+            bool ok = X[2] * X[3] > 0;
+            double Xn0 = X[0] / X[3], Xn1 = X[1] / X[3], Xn2 = X[2] / X[3];
+            ok = ok && (Xn2 < 50.0);
+            double z2 = Pm[2][0] * Xn0 + Pm[2][1] * Xn1 + Pm[2][2] * Xn2 + Pm[2][3];
+            ok = ok && (z2 > 0) && (z2 < 50.0) && inl;
+            bits |= (unsigned)ok << c;
+            my[c] += ok;
+        }
+        if (scratch_mask) scratch_mask[i] = (unsigned char)bits;
+    }
+    for (int c = 0; c < 4; ++c) {
+        int v = my[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) atomicAdd(&cnt[c], v);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int g1 = cnt[0], g2 = cnt[1], g3 = cnt[2], g4 = cnt[3], sl;
+        if (g1 >= g2 && g1 >= g3 && g1 >= g4) sl = 0;
+        else if (g2 >= g1 && g2 >= g3 && g2 >= g4) sl = 1;
+        else if (g3 >= g1 && g3 >= g2 && g3 >= g4) sl = 2;
+        else sl = 3;
+        sel = sl;
+        int good = cnt[sl];
+        if (r) {
+            if (good >= 10) {
+                r->valid = 1;
+                r->inliers = good;
+                for (int k = 0; k < 9; ++k) r->R[k] = sR[sl & 1][k];
+                for (int k = 0; k < 3; ++k) r->t[k] = (sl < 2 ? 1.0 : -1.0) * sT[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (scratch_mask) {
+        int sl = sel;
+        for (int i = tid; i < n; i += 256) scratch_mask[i] = (scratch_mask[i] >> sl) & 1;
+    }
+}
+
+static int round_size(int round, int fixed) {
+    if (fixed > 0) return 512;
+    static const int sz[] = {32, 96, 128, 256, 488};
+    return round < 5 ? sz[round] : 0;
+}
+
+int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
+               const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
+               double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
+               int samples_cap) {
+    if (batch <= 0) return VO_OK;
+    hipStream_t s = c->stream;
+    RParams P;
+    P.ifx = 1.0 / K[0];
+    P.ify = 1.0 / K[1];
+    P.bx = -K[2] * P.ifx;
+    P.by = -K[3] * P.ify;
+    P.fx_mean = (K[0] + K[1]) / 2;
+    P.threshold = threshold / P.fx_mean;
+    P.t2 = (float)(P.threshold * P.threshold);
+    P.confidence = confidence;
+    P.fixed_iters = fixed_iters;
+    const int HR = 512;   // largest round
+    int rc;
+    int nm = std::max(n_max, 1);
+    if ((rc = ensure(c, c->r_state, (size_t)batch * sizeof(RState)))) return rc;
+    if ((rc = ensure(c, c->r_pts, (size_t)batch * nm * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->r_samples, (size_t)batch * HR * 5 * 4))) return rc;
+    if ((rc = ensure(c, c->r_models, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->r_nmodels, (size_t)batch * HR * 4))) return rc;
+    if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
+    RState* st = (RState*)c->r_state.p;
+    double* m = (double*)c->r_pts.p;
+    int32_t* samples = (int32_t*)c->r_samples.p;
+    double* models = (double*)c->r_models.p;
+    int32_t* nmodels = (int32_t*)c->r_nmodels.p;
+    int32_t* counts = (int32_t*)c->r_counts.p;
+
+    if (n_max > 0)
+        hipLaunchKernelGGL(normalize_kernel, dim3((n_max + 255) / 256, batch), dim3(256), 0, s, d_p1, d_p2, d_n, n_max, P,
+                           m);
+    int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
+    int r0 = std::min(round_size(0, fixed_iters), total);
+    hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
+                       r0);
+    int h0 = 0;
+    for (int round = 0; h0 < total; ++round) {
+        int hr = std::min(round_size(round, fixed_iters), total - h0);
+        if (hr <= 0) break;
+        int next = std::min(round_size(round + 1, fixed_iters), total - (h0 + hr));
+        if (next < 0) next = 0;
+        hipLaunchKernelGGL(solve_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5, h0,
+                           hr, models, nmodels);
+        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2,
+                           counts);
+        hipLaunchKernelGGL(update_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
+                           counts, samples, HR * 5, next, d_samples, samples_cap);
+        h0 += hr;
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(256), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
+                       d_good);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+}  // namespace vo
+
+using namespace vo;
+
+static int run_host_ransac(vo_ctx* c, const float* p1, const float* p2, int n, const double K[4], double threshold,
+                           double confidence, int fixed_iters, vo_pair_result* res, double* E, uint8_t* mask_e,
+                           uint8_t* mask_pose, int32_t* good2, int32_t* samples, int samples_cap) {
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    int nm = std::max(n, 1);
+    if ((rc = ensure(c, c->m_p1, (size_t)nm * 8))) return rc;
+    if ((rc = ensure(c, c->m_p2, (size_t)nm * 8))) return rc;
+    size_t log_bytes = samples ? (size_t)samples_cap * 5 * 4 : 0;
+    size_t res_bytes = sizeof(vo_pair_result) + 9 * 8 + 2 * (size_t)nm + 64 + log_bytes + 64;
+    if ((rc = ensure(c, c->r_res, res_bytes))) return rc;
+    uint8_t* base = (uint8_t*)c->r_res.p;
+    vo_pair_result* d_res = (vo_pair_result*)base;
+    double* d_E = (double*)(base + sizeof(vo_pair_result));
+    int32_t* d_good = (int32_t*)(base + sizeof(vo_pair_result) + 72);
+    int32_t* d_samples = samples ? (int32_t*)(base + sizeof(vo_pair_result) + 72 + 64) : nullptr;
+    uint8_t* d_me = base + sizeof(vo_pair_result) + 72 + 64 + log_bytes;
+    uint8_t* d_mp = d_me + nm;
+    if (n > 0) {
+        VO_HIP(c, hipMemcpyAsync(c->m_p1.p, p1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        VO_HIP(c, hipMemcpyAsync(c->m_p2.p, p2, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (d_samples) VO_HIP(c, hipMemsetAsync(d_samples, 0xFF, log_bytes, c->stream));
+    if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, nullptr, n, 1, K, threshold, confidence,
+                         fixed_iters, d_res, d_E, d_me, d_mp, d_good, d_samples, samples_cap)))
+        return rc;
+    VO_HIP(c, hipMemcpyAsync(res, d_res, sizeof(vo_pair_result), hipMemcpyDeviceToHost, c->stream));
+    if (E) VO_HIP(c, hipMemcpyAsync(E, d_E, 72, hipMemcpyDeviceToHost, c->stream));
+    if (good2) VO_HIP(c, hipMemcpyAsync(good2, d_good, 8, hipMemcpyDeviceToHost, c->stream));
+    if (mask_e && n > 0) VO_HIP(c, hipMemcpyAsync(mask_e, d_me, n, hipMemcpyDeviceToHost, c->stream));
+    if (mask_pose && n > 0) VO_HIP(c, hipMemcpyAsync(mask_pose, d_mp, n, hipMemcpyDeviceToHost, c->stream));
+    if (samples) VO_HIP(c, hipMemcpyAsync(samples, d_samples, log_bytes, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_estimate_motion(vo_ctx* c, const float* p1, const float* p2, int n, const double K[4],
+                                  double threshold, double confidence, int fixed_iters, double R[9], double t[3],
+                                  int* inliers, int* valid, uint8_t* mask) {
+    if (!c) return VO_ERR_INVALID;
+    if (!inliers || !valid || !R || !t || !K || n < 0 || (n > 0 && (!p1 || !p2)))
+        return fail(c, VO_ERR_INVALID, "vo_estimate_motion: bad argument");
+    *inliers = 0;
+    *valid = 0;
+    if (n < 5) return VO_OK;   // fewer than min_essential_points -> invalid, not an error
+    vo_pair_result res;
+    int rc = run_host_ransac(c, p1, p2, n, K, threshold, confidence, fixed_iters, &res, nullptr, nullptr, mask, nullptr,
+                             nullptr, 0);
+    if (rc) return rc;
+    *valid = res.valid;
+    *inliers = res.inliers;
+    if (res.valid) {
+        for (int k = 0; k < 9; ++k) R[k] = res.R[k];
+        for (int k = 0; k < 3; ++k) t[k] = res.t[k];
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_find_essential(vo_ctx* c, const float* p1, const float* p2, int n, const double K[4],
+                                 double threshold, double confidence, int fixed_iters, double E[9], uint8_t* mask,
+                                 int* good, int* iters_run, int32_t* samples) {
+    if (!c) return VO_ERR_INVALID;
+    if (!good || !E || !K || n < 0 || (n > 0 && (!p1 || !p2)))
+        return fail(c, VO_ERR_INVALID, "vo_find_essential: bad argument");
+    *good = 0;
+    if (iters_run) *iters_run = 0;
+    if (n < 5) return VO_OK;
+    vo_pair_result res;
+    int32_t g2[2] = {0, 0};
+    int cap = std::max(1000, fixed_iters);
+    int rc = run_host_ransac(c, p1, p2, n, K, threshold, confidence, fixed_iters, &res, E, mask, nullptr, g2, samples,
+                             cap);
+    if (rc) return rc;
+    *good = g2[0];
+    if (iters_run) *iters_run = g2[1];
+    return VO_OK;
+}
