@@ -149,6 +149,13 @@ int vo_debug_level(vo_ctx* ctx, int image, int level, int blurred, uint8_t* out,
  * particular order.  Returns the count in *n_out. */
 int vo_debug_candidates(vo_ctx* ctx, int image, int level, int32_t* out, int cap, int* n_out);
 
+/* The five-point minimal solver alone: `count` sets of 5 correspondences in
+ * normalised image coordinates (x1, x2: count x 5 x 2 doubles).  Es receives
+ * count x 10 x 9 doubles (unit-norm essential matrices, row-major, ascending
+ * in the hidden variable), n_models the number found per set. */
+int vo_debug_five_point(vo_ctx* ctx, const double* x1, const double* x2, int count, double* Es,
+                        int32_t* n_models);
+
 #ifdef __cplusplus
 }
 #endif

@@ -673,9 +673,109 @@ const int kMono[20][3] = {{3, 0, 0}, {0, 3, 0}, {2, 1, 0}, {1, 2, 0}, {2, 0, 1},
                           {0, 2, 0}, {1, 1, 1}, {1, 1, 0}, {1, 0, 2}, {1, 0, 1}, {1, 0, 0}, {0, 1, 2},
                           {0, 1, 1}, {0, 1, 0}, {0, 0, 3}, {0, 0, 2}, {0, 0, 1}, {0, 0, 0}};
 
+// f(E) = [det E ; 2 E E^T E - trace(E E^T) E] : the ten cubic constraints an
+// essential matrix satisfies, and their derivative along a direction D.
+void essential_constraints(const double* E, double* f) {
+    double EEt[9], T[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += E[i * 3 + k] * E[j * 3 + k];
+            EEt[i * 3 + j] = s;
+        }
+    double tr = EEt[0] + EEt[4] + EEt[8];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += EEt[i * 3 + k] * E[k * 3 + j];
+            T[i * 3 + j] = 2 * s - tr * E[i * 3 + j];
+        }
+    f[0] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+    for (int k = 0; k < 9; ++k) f[1 + k] = T[k];
+}
+void essential_constraints_dir(const double* E, const double* D, double* df) {
+    // d det = trace(adj(E) D); d(2EE^TE - tr(EE^T)E) = 2(DE^TE + ED^TE + EE^TD) - 2 tr(ED^T) E - tr(EE^T) D
+    double C[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                   E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                   E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};  // cofactors
+    double dd = 0;
+    for (int k = 0; k < 9; ++k) dd += C[k] * D[k];
+    df[0] = dd;
+    double EtE[9], EEt[9], DtE[9];
+    double trEEt = 0, trEDt = 0;
+    for (int k = 0; k < 9; ++k) { trEEt += E[k] * E[k]; trEDt += E[k] * D[k]; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0, b = 0, c = 0;
+            for (int k = 0; k < 3; ++k) {
+                a += E[k * 3 + i] * E[k * 3 + j];   // E^T E
+                b += E[i * 3 + k] * E[j * 3 + k];   // E E^T
+                c += D[k * 3 + i] * E[k * 3 + j];   // D^T E
+            }
+            EtE[i * 3 + j] = a; EEt[i * 3 + j] = b; DtE[i * 3 + j] = c;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k)
+                s += D[i * 3 + k] * EtE[k * 3 + j] + E[i * 3 + k] * DtE[k * 3 + j] + EEt[i * 3 + k] * D[k * 3 + j];
+            df[1 + i * 3 + j] = 2 * s - 2 * trEDt * E[i * 3 + j] - trEEt * D[i * 3 + j];
+        }
+}
+
+// Gauss-Newton refinement of (x,y,z) on the ten constraints for
+// E = x*B0 + y*B1 + z*B2 + B3.  OpenCV does not do this: its Durand-Kerner
+// root finder stops after 300 sweeps whether converged or not, which leaves a
+// few percent of the models accurate to 3-4 digits only.  Refining makes every
+// model the exact solution of the five-point problem to rounding, which is the
+// quantity any correct solver must agree on.  Returns the largest constraint
+// residual of the unit-norm result.
+double polish_model(const double* const B[4], double* xyz, double* Eout) {
+    double E[9];
+    for (int it = 0; it <= 4; ++it) {
+        for (int k = 0; k < 9; ++k) E[k] = B[0][k] * xyz[0] + B[1][k] * xyz[1] + B[2][k] * xyz[2] + B[3][k];
+        if (it == 4) break;
+        double f[10], J[3][10];
+        essential_constraints(E, f);
+        for (int c = 0; c < 3; ++c) essential_constraints_dir(E, B[c], J[c]);
+        double N[3][3], g[3];
+        for (int a = 0; a < 3; ++a) {
+            g[a] = 0;
+            for (int k = 0; k < 10; ++k) g[a] += J[a][k] * f[k];
+            for (int b = 0; b < 3; ++b) {
+                double s = 0;
+                for (int k = 0; k < 10; ++k) s += J[a][k] * J[b][k];
+                N[a][b] = s;
+            }
+        }
+        double lam = 1e-14 * (N[0][0] + N[1][1] + N[2][2]);
+        for (int a = 0; a < 3; ++a) N[a][a] += lam;
+        double det = N[0][0] * (N[1][1] * N[2][2] - N[1][2] * N[2][1]) - N[0][1] * (N[1][0] * N[2][2] - N[1][2] * N[2][0]) +
+                     N[0][2] * (N[1][0] * N[2][1] - N[1][1] * N[2][0]);
+        if (!(std::fabs(det) > 0)) break;
+        double inv = 1.0 / det;
+        double d0 = (g[0] * (N[1][1] * N[2][2] - N[1][2] * N[2][1]) - N[0][1] * (g[1] * N[2][2] - N[1][2] * g[2]) +
+                     N[0][2] * (g[1] * N[2][1] - N[1][1] * g[2])) * inv;
+        double d1 = (N[0][0] * (g[1] * N[2][2] - N[1][2] * g[2]) - g[0] * (N[1][0] * N[2][2] - N[1][2] * N[2][0]) +
+                     N[0][2] * (N[1][0] * g[2] - g[1] * N[2][0])) * inv;
+        double d2 = (N[0][0] * (N[1][1] * g[2] - g[1] * N[2][1]) - N[0][1] * (N[1][0] * g[2] - g[1] * N[2][0]) +
+                     g[0] * (N[1][0] * N[2][1] - N[1][1] * N[2][0])) * inv;
+        xyz[0] -= d0; xyz[1] -= d1; xyz[2] -= d2;
+    }
+    double nrm = 0;
+    for (int k = 0; k < 9; ++k) nrm += E[k] * E[k];
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0) || !std::isfinite(nrm)) return 1e300;
+    for (int k = 0; k < 9; ++k) Eout[k] = E[k] / nrm;
+    double f[10], r = 0;
+    essential_constraints(Eout, f);
+    for (int k = 0; k < 10; ++k) r = std::max(r, std::fabs(f[k]));
+    return r;
+}
+
 // EMEstimatorCallback::runKernel: x1,x2 are 5 normalised points (x,y).
 // Writes up to 10 essential matrices (row-major 3x3, unit Frobenius norm).
-int five_point(const double* x1, const double* x2, double* Es) {
+int five_point(const double* x1, const double* x2, double* Es, double* dbg = nullptr) {
     // Q (5 x 9): rows x2^T E x1 = 0 in the order [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]
     double Qt[9 * 5];  // Q transposed, 9 x 5
     for (int i = 0; i < 5; ++i) {
@@ -775,9 +875,17 @@ int five_point(const double* x1, const double* x2, double* Es) {
         for (int i = 0; i <= d0 + d1 + d2; ++i) c[i] += sgn[p] * t[i];
     }
     std::vector<std::complex<double>> roots = solve_poly(c, 10);
+    if (dbg) {
+        for (int i = 0; i < 11; ++i) dbg[i] = c[i];
+        for (size_t i = 0; i < roots.size() && i < 10; ++i) { dbg[11 + 2 * i] = roots[i].real(); dbg[12 + 2 * i] = roots[i].imag(); }
+        dbg[31] = (double)roots.size();
+    }
     int count = 0;
     for (auto& rt : roots) {
-        if (std::fabs(rt.imag()) > 1e-10) continue;
+        // OpenCV keeps a root only if |imag| <= 1e-10.  Durand-Kerner is often short of
+        // that on clustered roots after its 300 sweeps, so the gate here is loose and the
+        // refinement below (which rejects starts that do not settle) decides instead.
+        if (std::fabs(rt.imag()) > 1e-3 * std::max(1.0, std::fabs(rt.real()))) continue;
         double z1 = rt.real(), z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
         for (int j = 0; j < 3; ++j) {
@@ -791,14 +899,21 @@ int five_point(const double* x1, const double* x2, double* Es) {
         jacobi_svd(bz, 3, 3, sw, sU, sV);
         double xy1[3] = {sV[0 * 3 + 2], sV[1 * 3 + 2], sV[2 * 3 + 2]};
         if (std::fabs(xy1[2]) < 1e-10) continue;
-        double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2];
-        double Ev[9], nrm = 0;
-        for (int k = 0; k < 9; ++k) {
-            Ev[k] = EE[0][k] * x + EE[1][k] * y + EE[2][k] * z1 + EE[3][k];
-            nrm += Ev[k] * Ev[k];
+        double xyz[3] = {xy1[0] / xy1[2], xy1[1] / xy1[2], z1};
+        double Ev[9];
+        double res = polish_model(EE, xyz, Ev);
+        if (!(res <= 1e-9)) continue;          // did not settle on a solution
+        bool dup = false;                      // two starts that settled on the same solution
+        for (int m = 0; m < count && !dup; ++m) {
+            double dp = 0, dm = 0;
+            for (int k = 0; k < 9; ++k) {
+                dp = std::max(dp, std::fabs(Es[m * 9 + k] - Ev[k]));
+                dm = std::max(dm, std::fabs(Es[m * 9 + k] + Ev[k]));
+            }
+            dup = std::min(dp, dm) < 1e-7;
         }
-        nrm = std::sqrt(nrm);
-        for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k] / nrm;
+        if (dup) continue;
+        for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k];
         ++count;
         if (count == 10) break;
     }
@@ -1068,6 +1183,12 @@ int oracle_match(const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio
 }
 
 int oracle_five_point(const double* x1, const double* x2, double* Es) { return five_point(x1, x2, Es); }
+
+// Same, also returning the degree-10 polynomial (dbg[0..10], ascending), the raw
+// Durand-Kerner roots (dbg[11..30] as re,im pairs) and their number (dbg[31]).
+int oracle_five_point_debug(const double* x1, const double* x2, double* Es, double* dbg) {
+    return five_point(x1, x2, Es, dbg);
+}
 
 int oracle_find_essential(const float* p1, const float* p2, int n, const double* K, double threshold,
                           double confidence, int max_iters, int fixed_iters, double* E, uint8_t* mask,

@@ -24,7 +24,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_last_kernel_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
-    "vo_pipeline_pairs_dev", "vo_debug_level", "vo_debug_candidates",
+    "vo_pipeline_pairs_dev", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
 
 _lib = None
@@ -41,6 +41,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise VoError(f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950)")
+    # PyTorch wheels carry their own libamdhip64.so.7.  Whichever copy is mapped first
+    # serves the whole process, and torch only finds the GPU when it is its own copy, so
+    # torch (used by callers for device buffers and torch.distributed) goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i, f, d, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
     lib.vo_ctx_create.argtypes = [i, C.POINTER(vp)]
@@ -64,6 +71,7 @@ def load():
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_debug_level.argtypes = [vp, i, i, i, vp, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
+    lib.vo_debug_five_point.argtypes = [vp, vp, vp, i, vp, vp]
     _lib = lib
     return lib
 
@@ -188,6 +196,16 @@ class Context:
                                                int(fixed_iters), _p(E), _p(mask), C.byref(good), C.byref(iters),
                                                _p(samples)), "vo_find_essential")
         return good.value, E, mask[:n], iters.value, samples[: iters.value]
+
+    def five_point(self, x1, x2):
+        """x1, x2: (count, 5, 2) normalised points.  Returns a list of (k, 3, 3) arrays."""
+        x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 5, 2)
+        x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 5, 2)
+        cnt = len(x1)
+        Es = np.zeros((cnt, 10, 3, 3))
+        nm = np.zeros(cnt, np.int32)
+        self._check(self.lib.vo_debug_five_point(self.h, _p(x1), _p(x2), cnt, _p(Es), _p(nm)), "vo_debug_five_point")
+        return [Es[i, : nm[i]].copy() for i in range(cnt)]
 
     # ---- device-resident entry points (pointers are integers / c_void_p) ---------
     def orb_detect_batch_dev(self, d_imgs, n_images, rows, cols, step, image_stride, max_features, d_kps, d_desc,

@@ -117,7 +117,7 @@ __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__
 constexpr int ST = 64;   // lanes per solve workgroup (one hypothesis each)
 
 // quad[10] (+)= s * a[4] (x) b[4]
-__device__ __forceinline__ void mul_ll(const double* a, const double* b, double s, double* q) {
+__host__ __device__ __forceinline__ void mul_ll(const double* a, const double* b, double s, double* q) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ __forceinline__ void mul_ll(const double* a, const double* b, double 
 }
 
 // row of A (LDS, stride ST doubles) += s * q[10] (x) l[4]
-__device__ __forceinline__ void mul_ql_row(const double* q, const double* l, double s, double* row) {
+__host__ __device__ __forceinline__ void mul_ql_row(const double* q, const double* l, double s, double* row) {
 #pragma unroll
     for (int i = 0; i < 10; ++i)
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ void mul_ql_row(const double* q, const double* l, dou
 }
 
 // j-th derivative of the polynomial c (degree n) at x; dc[j] holds its coefficients.
-__device__ __forceinline__ double poly_eval(const double* d, int deg, double x) {
+__host__ __device__ __forceinline__ double poly_eval(const double* d, int deg, double x) {
     double v = d[deg];
     for (int i = deg - 1; i >= 0; --i) v = v * x + d[i];
     return v;
@@ -150,10 +150,12 @@ __device__ __forceinline__ double poly_eval(const double* d, int deg, double x) 
 // Real roots (ascending) of c[0..10] by derivative interlacing: the roots of
 // each derivative bracket the monotone pieces of the next lower one, and
 // every bracket with a sign change is closed by a Newton/bisection hybrid.
-__device__ int real_roots(const double* c, double* roots) {
+// Extrema of the polynomial itself that vanish to rounding level are reported
+// as (double) roots; roots closer than 1e-7 relative are reported once.
+__host__ __device__ int real_roots(const double* c, double* roots) {
     double cmax = 0;
     for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(c[i]));
-    if (!(cmax > 0) || !isfinite(cmax)) return 0;
+    if (!(cmax > 0) || !(cmax < DBL_MAX)) return 0;
     int n = 10;
     while (n > 0 && fabs(c[n]) <= 1e-14 * cmax) --n;
     if (n == 0) return 0;
@@ -204,8 +206,17 @@ __device__ int real_roots(const double* c, double* roots) {
                         if (f == 0.0) break;
                         if (f < 0.0) xl = x; else xh = x;
                     }
-                    if (nc < 10) cur[nc++] = x;
+                    bool dup = j == 0 && nc > 0 && fabs(x - cur[nc - 1]) <= 1e-7 * fmax(1.0, fabs(x));
+                    if (nc < 10 && !dup) cur[nc++] = x;
                 }
+            }
+            if (j == 0 && k < np && fb != 0.0) {
+                // A local extremum that touches zero to rounding level is a double root
+                // (exactly degenerate data, e.g. pure sideways translation): keep it.
+                double mag = fabs(d[deg]), ab = fabs(b);
+                for (int i = deg - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
+                bool dup = nc > 0 && fabs(b - cur[nc - 1]) <= 1e-7 * fmax(1.0, ab);
+                if (fabs(fb) <= 1e-6 * mag && !dup && nc < 10) cur[nc++] = b;
             }
             if (b > a) {
                 a = b;
@@ -220,10 +231,108 @@ __device__ int real_roots(const double* c, double* roots) {
     return np;
 }
 
+// The ten cubic constraints on an essential matrix, f(E) = [det E ;
+// 2 E E^T E - trace(E E^T) E], and (dir != nullptr) their derivative along D.
+__host__ __device__ __forceinline__ void ess_constraints(const double* E, double* f) {
+    double G[9];   // E E^T
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) G[i * 3 + j] = E[i * 3] * E[j * 3] + E[i * 3 + 1] * E[j * 3 + 1] + E[i * 3 + 2] * E[j * 3 + 2];
+    double tr = G[0] + G[4] + G[8];
+    f[0] = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            f[1 + i * 3 + j] = 2.0 * (G[i * 3] * E[j] + G[i * 3 + 1] * E[3 + j] + G[i * 3 + 2] * E[6 + j]) - tr * E[i * 3 + j];
+}
+
+__host__ __device__ __forceinline__ void ess_constraints_dir(const double* E, const double* D, double* df) {
+    const double C[9] = {E[4] * E[8] - E[5] * E[7], E[5] * E[6] - E[3] * E[8], E[3] * E[7] - E[4] * E[6],
+                         E[2] * E[7] - E[1] * E[8], E[0] * E[8] - E[2] * E[6], E[1] * E[6] - E[0] * E[7],
+                         E[1] * E[5] - E[2] * E[4], E[2] * E[3] - E[0] * E[5], E[0] * E[4] - E[1] * E[3]};
+    double dd = 0, trEE = 0, trED = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        dd += C[k] * D[k];
+        trEE += E[k] * E[k];
+        trED += E[k] * D[k];
+    }
+    df[0] = dd;
+    double EtE[9], EEt[9], DtE[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            EtE[i * 3 + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+            EEt[i * 3 + j] = E[i * 3] * E[j * 3] + E[i * 3 + 1] * E[j * 3 + 1] + E[i * 3 + 2] * E[j * 3 + 2];
+            DtE[i * 3 + j] = D[i] * E[j] + D[3 + i] * E[3 + j] + D[6 + i] * E[6 + j];
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                s += D[i * 3 + k] * EtE[k * 3 + j] + E[i * 3 + k] * DtE[k * 3 + j] + EEt[i * 3 + k] * D[k * 3 + j];
+            df[1 + i * 3 + j] = 2.0 * s - 2.0 * trED * E[i * 3 + j] - trEE * D[i * 3 + j];
+        }
+}
+
+// Four Gauss-Newton steps on (x,y,z) for E = x*B0 + y*B1 + z*B2 + B3 against
+// the ten constraints, so that every model returned is the exact solution of
+// the five-point problem to rounding whatever the conditioning of the
+// elimination that produced the starting point.  Returns the largest
+// constraint residual of the unit-norm result written to Eout.
+__host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout) {
+    double E[9];
+    for (int it = 0; it <= 4; ++it) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = B[0][k] * x + B[1][k] * y + B[2][k] * z + B[3][k];
+        if (it == 4) break;
+        double f[10], J0[10], J1[10], J2[10];
+        ess_constraints(E, f);
+        ess_constraints_dir(E, B[0], J0);
+        ess_constraints_dir(E, B[1], J1);
+        ess_constraints_dir(E, B[2], J2);
+        double n00 = 0, n01 = 0, n02 = 0, n11 = 0, n12 = 0, n22 = 0, g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            n00 += J0[k] * J0[k]; n01 += J0[k] * J1[k]; n02 += J0[k] * J2[k];
+            n11 += J1[k] * J1[k]; n12 += J1[k] * J2[k]; n22 += J2[k] * J2[k];
+            g0 += J0[k] * f[k]; g1 += J1[k] * f[k]; g2 += J2[k] * f[k];
+        }
+        double lam = 1e-14 * (n00 + n11 + n22);
+        n00 += lam; n11 += lam; n22 += lam;
+        double c00 = n11 * n22 - n12 * n12, c01 = n01 * n22 - n12 * n02, c02 = n01 * n12 - n11 * n02;
+        double det = n00 * c00 - n01 * c01 + n02 * c02;
+        if (!(fabs(det) > 0)) break;
+        double inv = 1.0 / det;
+        double d0 = (g0 * c00 - n01 * (g1 * n22 - n12 * g2) + n02 * (g1 * n12 - n11 * g2)) * inv;
+        double d1 = (n00 * (g1 * n22 - n12 * g2) - g0 * c01 + n02 * (n01 * g2 - g1 * n02)) * inv;
+        double d2 = (n00 * (n11 * g2 - g1 * n12) - n01 * (n01 * g2 - g1 * n02) + g0 * c02) * inv;
+        x -= d0; y -= d1; z -= d2;
+    }
+    double nrm = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) nrm += E[k] * E[k];
+    nrm = sqrt(nrm);
+    if (!(nrm > 0) || !(nrm < DBL_MAX)) return 1e300;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Eout[k] = E[k] / nrm;
+    double f[10], r = 0;
+    ess_constraints(Eout, f);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) r = fmax(r, fabs(f[k]));
+    return r;
+}
+
 // x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm
 // essential matrices (row-major) to Es.  sA: this lane's column of the
 // 10x20 elimination matrix in LDS (element (r,c) at sA[(r*20+c)*ST]).
-__device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
+__host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
     // ---- null space of the 5x9 epipolar constraint matrix (Householder QR of its transpose)
     double M[9][5];
 #pragma unroll
@@ -272,6 +381,20 @@ __device__ int five_point_dev(const double* x1, const double* x2, double* __rest
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) EE[t][i] = e[i];
+    }
+    // The Householder basis inherits structure from the data (two equal rows of
+    // the constraint matrix, as under pure sideways translation, put the true
+    // solution exactly at infinity of the chart w = 1 used below).  Mixing the
+    // four vectors with a fixed dense orthogonal matrix (I - 2uu^T,
+    // u ~ (1, sqrt2, sqrt3, sqrt5)) removes such alignments.
+    {
+        const double u[4] = {0.30151134457776363, 0.42640143271122088, 0.52223296786709361, 0.67419986246324204};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            double dot = u[0] * EE[0][i] + u[1] * EE[1][i] + u[2] * EE[2][i] + u[3] * EE[3][i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) EE[t][i] -= 2.0 * u[t] * dot;
+        }
     }
     // ---- ten cubic constraints in (x,y,z) on E = x*EE0 + y*EE1 + z*EE2 + EE3
     double El[9][4];
@@ -427,17 +550,22 @@ __device__ int five_point_dev(const double* x1, const double* x2, double* __rest
         double inv = 1.0 / sqrt(bn);
         bx *= inv; by *= inv; bw *= inv;
         if (fabs(bw) < 1e-10) continue;
-        double x = bx / bw, y = by / bw;
-        double Ev[9], nrm = 0;
+        double Ev[9];
+        double res = polish_model_dev(EE, bx / bw, by / bw, z1, Ev);
+        if (!(res <= 1e-9)) continue;   // did not settle on a solution
+        bool dup = false;               // two starts that settled on the same solution
+        for (int m = 0; m < count && !dup; ++m) {
+            double dp = 0, dm = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            Ev[k] = EE[0][k] * x + EE[1][k] * y + EE[2][k] * z1 + EE[3][k];
-            nrm += Ev[k] * Ev[k];
+            for (int k = 0; k < 9; ++k) {
+                dp = fmax(dp, fabs(Es[m * 9 + k] - Ev[k]));
+                dm = fmax(dm, fabs(Es[m * 9 + k] + Ev[k]));
+            }
+            dup = fmin(dp, dm) < 1e-7;
         }
-        nrm = sqrt(nrm);
-        if (!(nrm > 0) || !isfinite(nrm)) continue;
+        if (dup) continue;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k] / nrm;
+        for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k];
         ++count;
     }
     return count;
@@ -790,6 +918,22 @@ __global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ 
     }
 }
 
+// Five-point solver alone on caller-supplied minimal sets (normalised coordinates).
+__global__ __launch_bounds__(ST) void five_point_debug_kernel(const double* __restrict__ x1,
+                                                              const double* __restrict__ x2, int count,
+                                                              double* __restrict__ models,
+                                                              int32_t* __restrict__ nmodels) {
+    __shared__ double sA[200 * ST];
+    int h = blockIdx.x * ST + threadIdx.x;
+    if (h >= count) return;
+    double a[10], b[10];
+    for (int i = 0; i < 10; ++i) {
+        a[i] = x1[h * 10 + i];
+        b[i] = x2[h * 10 + i];
+    }
+    nmodels[h] = five_point_dev(a, b, models + (size_t)h * kMaxModels * 9, sA + threadIdx.x);
+}
+
 static int round_size(int round, int fixed) {
     if (fixed > 0) return 512;
     static const int sz[] = {32, 96, 128, 256, 488};
@@ -934,5 +1078,28 @@ extern "C" int vo_find_essential(vo_ctx* c, const float* p1, const float* p2, in
     if (rc) return rc;
     *good = g2[0];
     if (iters_run) *iters_run = g2[1];
+    return VO_OK;
+}
+
+extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2, int count, double* Es,
+                                   int32_t* n_models) {
+    if (!c) return VO_ERR_INVALID;
+    if (count <= 0 || !x1 || !x2 || !Es || !n_models) return fail(c, VO_ERR_INVALID, "vo_debug_five_point: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    size_t in_b = (size_t)count * 10 * 8, out_b = (size_t)count * kMaxModels * 9 * 8;
+    if ((rc = ensure(c, c->r_pts, 2 * in_b))) return rc;
+    if ((rc = ensure(c, c->r_models, out_b))) return rc;
+    if ((rc = ensure(c, c->r_nmodels, (size_t)count * 4))) return rc;
+    double* d_in = (double*)c->r_pts.p;
+    VO_HIP(c, hipMemcpyAsync(d_in, x1, in_b, hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(d_in + (size_t)count * 10, x2, in_b, hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemsetAsync(c->r_models.p, 0, out_b, c->stream));
+    hipLaunchKernelGGL(five_point_debug_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
+                       d_in + (size_t)count * 10, count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
+    VO_HIP(c, hipGetLastError());
+    VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(n_models, c->r_nmodels.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
     return VO_OK;
 }

@@ -4,11 +4,25 @@ The datasets the reference is run on (TUM fr1_xyz, KITTI) cannot be fetched, so
 frames are generated: a layered scene of textured rectangles at different
 depths, seen by a camera that translates along +x between the two frames
 (every layer shifts left by its own integer disparity, 12-40 px, so that
-triangulated depths stay below recoverPose's 50-baseline cut-off), plus independent pixel
+triangulated depths stay below recoverPose's 50-baseline cut-off) and also rotates
+a little (an exact homography warp of the second frame), plus independent pixel
 noise per frame.  The two views therefore obey a real two-view geometry
 (R = I, t along x) and FAST fires densely at every pyramid level.
 """
 import numpy as np
+
+
+TUM_K = (517.3, 516.5, 318.6, 255.3)         # ref:data/tum/README.md:57-58
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # ref:data/README.md:30-33
+
+
+def default_K(width, height):
+    """Intrinsics (fx, fy, cx, cy) used for a synthetic frame of this shape."""
+    if (width, height) == (640, 480):
+        return TUM_K
+    if (width, height) == (1241, 376):
+        return KITTI_K
+    return (0.8 * width, 0.8 * width, width / 2.0, height / 2.0)
 
 
 def _texture(rng, h, w):
@@ -21,8 +35,37 @@ def _texture(rng, h, w):
     return img
 
 
-def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0):
-    """Returns (frame_a, frame_b) as uint8 arrays of shape (height, width)."""
+def _rotation(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _warp_rotation(img, K, R):
+    """View of the same scene after rotating the camera by R (x_new = K R K^-1 x_old):
+    exact for any depth, so it composes with the translational parallax. Bilinear."""
+    h, w = img.shape
+    fx, fy, cx, cy = K
+    Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    Hinv = Km @ R.T @ np.linalg.inv(Km)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = Hinv[2, 0] * xs + Hinv[2, 1] * ys + Hinv[2, 2]
+    sx = np.clip((Hinv[0, 0] * xs + Hinv[0, 1] * ys + Hinv[0, 2]) / d, 0, w - 1.001)
+    sy = np.clip((Hinv[1, 0] * xs + Hinv[1, 1] * ys + Hinv[1, 2]) / d, 0, h - 1.001)
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    ax, ay = sx - x0, sy - y0
+    return ((1 - ay) * ((1 - ax) * img[y0, x0] + ax * img[y0, x0 + 1]) +
+            ay * ((1 - ax) * img[y0 + 1, x0] + ax * img[y0 + 1, x0 + 1]))
+
+
+def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0, K=None, rot_deg=(0.4, -0.7, 1.1)):
+    """Returns (frame_a, frame_b) as uint8 arrays of shape (height, width).
+
+    rot_deg: camera rotation (about x, y, z, degrees) between the frames, applied on
+    top of the sideways translation; (0, 0, 0) leaves the exactly degenerate
+    pure-translation geometry with horizontal integer disparities."""
     rng = np.random.default_rng(seed)
     pad = 48
     W = width + 2 * pad
@@ -39,6 +82,9 @@ def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0):
         b[y:y + h, x - d:x - d + w] = tex
     a = a[:, pad:pad + width]
     b = b[:, pad:pad + width]
+    if any(rot_deg):
+        Kc = K if K is not None else default_K(width, height)
+        b = _warp_rotation(b, Kc, _rotation(*np.radians(rot_deg)))
     a = a + rng.normal(0.0, noise, a.shape)
     b = b + rng.normal(0.0, noise, b.shape)
     return (np.clip(np.rint(a), 0, 255).astype(np.uint8),
@@ -74,5 +120,3 @@ def descriptors(seed, n, dup_fraction=0.01):
     return d
 
 
-TUM_K = (517.3, 516.5, 318.6, 255.3)         # ref:data/tum/README.md:57-58
-KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # ref:data/README.md:30-33
