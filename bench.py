@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X visual-odometry front end.
+
+One step = one pass of the fused hot path (ORB detect x2 -> Hamming kNN(2) +
+ratio test -> essential-matrix RANSAC + pose) over a batch of synthetic frame
+pairs that already sit in HBM.  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Frame pairs are independent, so ranks shard them with no data-path collective
+(weak scaling: every rank processes --pairs pairs per step).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (height, width, max_features, fixed_iters, default pairs per step)
+    "c2_640x480_2000kp": (480, 640, 2000, 0, 64),
+    "c3_kitti_1241x376_4000kp": (376, 1241, 4000, 0, 32),
+    "c5_1080p_10000kp_4096hyp": (1080, 1920, 10000, 4096, 8),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def level_pixels(h, w):
+    tot = 0
+    for l in range(8):
+        s = np.float32(1.2) ** l
+        tot += int(np.rint(np.float32(w) / np.float32(s))) * int(np.rint(np.float32(h) / np.float32(s)))
+    return tot
+
+
+def cpu_baseline(frames, K, max_features, fixed_iters, budget_s=20.0):
+    """The CPU oracle (scalar port of the reference path) on the same frames, one thread."""
+    from oracle import oracle as O
+    n_done, t0 = 0, time.perf_counter()
+    t_match_only = 0.0
+    while n_done < len(frames) // 2 and time.perf_counter() - t0 < budget_s:
+        a, b = frames[2 * n_done], frames[2 * n_done + 1]
+        t1 = time.perf_counter()
+        ka, da = O.orb_detect(a, max_features)
+        kb, db = O.orb_detect(b, max_features)
+        qi, ti, _ = O.match(da, db)
+        t_match_only += time.perf_counter() - t1
+        p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
+        p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
+        O.estimate_motion(p1, p2, K, fixed_iters=fixed_iters)
+        n_done += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+        "sample": f"{n_done} of the benchmark's frame pairs, detect x2 + match + E-RANSAC + pose, "
+                  f"{dt:.1f} s on one host thread (oracle/vo_oracle.cpp, g++ -O2)",
+        "ms_per_match_images": 1e3 * t_match_only / max(n_done, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2_640x480_2000kp", choices=list(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled up to --pairs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hamming", action="store_true")
+    args = ap.parse_args()
+
+    import torch   # before the HIP library: one HIP runtime for both
+    import torch.distributed as dist
+    from visual_odometry_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    H, W, nfeat, fixed, default_pairs = WORKLOADS[args.workload]
+    P = args.pairs or default_pairs
+    K = synth.default_K(W, H)
+    n_distinct = max(1, min(args.distinct, P))
+    frames = []
+    for p in range(n_distinct):
+        a, b = synth.frame_pair(0x5EED0000 + 1000 * rank + p, height=H, width=W)
+        frames += [a, b]
+    tiled = [frames[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)]
+    imgs = torch.from_numpy(np.stack(tiled)).cuda()
+    res = torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+
+    ctx = capi.Context(local_rank)
+
+    def step():
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+                               res.data_ptr())
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_timing(True)   # drop the warm-up launches from the per-kernel event statistics
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = {name: ctx.kernel_time_ms(g)[0] for g, name in enumerate(capi.T_GROUPS)}
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    total_pairs = P * args.steps * world
+    value = total_pairs / dt
+
+    # roofline of the dominant kernel (FAST-9 + NMS over every pyramid level): it reads each
+    # level pixel once and writes a sparse candidate list; algorithmic bytes per launch =
+    # level pixels of all images of the step.
+    pix = level_pixels(H, W)
+    fast_bytes = 2 * P * pix
+    fast_avg_ms = kernel_ms["fast"]
+    achieved = fast_bytes / (fast_avg_ms * 1e-3) / 1e9
+    line = {
+        "metric": "frame-pairs/sec (ORB+match+E-RANSAC, 640x480, 2k kps) + Hamming match GB/s",
+        "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": args.workload, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct,
+                   "image": f"{W}x{H}", "max_features": nfeat, "ratio": 0.75,
+                   "ransac": "adaptive<=1000" if fixed == 0 else f"fixed {fixed}", "parallelism": f"pairs x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": fast_avg_ms, "algorithmic_bytes_per_launch": fast_bytes},
+        "pipeline": {"mean_keypoints": float(np.mean(out["n_kp1"])), "mean_matches": float(np.mean(out["n_matches"])),
+                     "mean_inliers": float(np.mean(out["inliers"])), "valid_fraction": float(np.mean(out["valid"])),
+                     "mean_ransac_iters": float(np.mean(out["ransac_iters"])),
+                     "kernel_group_ms_per_step": kernel_ms},
+    }
+
+    if not args.no_hamming:
+        # second half of the metric: brute-force Hamming kNN(2), 65 536 x 65 536 descriptors
+        # (query rows sharded over ranks, train set replicated, results gathered on rank 0)
+        nq_total, nt = 65536, 65536
+        nq = nq_total // world
+        q = torch.from_numpy(synth.descriptors(7, nq_total)[rank * nq:(rank + 1) * nq]).cuda()
+        tr = torch.from_numpy(synth.descriptors(8, nt)).cuda()
+        idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+        dst = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            ctx.hamming_knn2_dev(q.data_ptr(), nq, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+        fence()
+        reps = 5
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.hamming_knn2_dev(q.data_ptr(), nq, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+        ctx.sync()
+        if world > 1:
+            gathered = [torch.empty_like(idx) for _ in range(world)] if rank == 0 else None
+            dist.gather(idx, gathered, dst=0)     # the one collective: matches to rank 0
+        fence()
+        hd = (time.perf_counter() - t0) / reps
+        t = torch.tensor([hd], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hd = float(t.item())
+        alg_bytes = float(nq_total) * nt * 32
+        line["hamming"] = {"workload": "c4_hamming_65536x65536", "value": alg_bytes / hd / 1e9,
+                           "unit": "GB/s (Nq*Nt*32 B / s)", "pair_compares_per_s": float(nq_total) * nt / hd,
+                           "ms": 1e3 * hd, "kernel_ms_rank0": ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0],
+                           "lane_ops_per_s": 19.0 * nq_total * nt / hd,
+                           "compulsory_hbm_bytes": (nq_total + nt) * 32 + nq_total * 16}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(frames, K, nfeat, fixed)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,11 +63,25 @@ const char* vo_last_error(const vo_ctx* ctx);
 /* hipStream_t the context enqueues on (as void*). */
 void* vo_ctx_stream(vo_ctx* ctx);
 int vo_sync(vo_ctx* ctx);
-/* Milliseconds (HIP events on the context's stream) the most recent call
- * spent in its dominant kernel: FAST for detection, the top-2 kernel for
- * matching.  -1 if timing was not enabled with vo_set_timing(ctx, 1). */
+/* Kernel timing with HIP events recorded on the context's stream.  While
+ * enabled, every launch of an instrumented kernel group is bracketed by a
+ * fresh event pair (nothing waits on them, so the pipeline is not perturbed).
+ * vo_kernel_time_ms() waits for the stream, then returns the mean duration in
+ * milliseconds over the launches recorded since timing was (re-)enabled and
+ * their number in *launches; -1 if none.  Groups: */
+enum {
+    VO_T_RESIZE = 0,   /* the seven pyramid resize launches of one detect call */
+    VO_T_FAST = 1,     /* FAST-9 + NMS + border filter, all levels */
+    VO_T_SELECT = 2,   /* score / Harris selection + orientation */
+    VO_T_BLUR = 3,     /* 7x7 blur, all levels */
+    VO_T_DESCRIBE = 4, /* rBRIEF + keypoint assembly */
+    VO_T_KNN2 = 5,     /* Hamming top-2 */
+    VO_T_RATIO = 6,    /* ratio test + compaction */
+    VO_T_RANSAC = 7,   /* all RANSAC and pose kernels of one call */
+    VO_T_COUNT = 8
+};
 int vo_set_timing(vo_ctx* ctx, int enabled);
-float vo_last_kernel_ms(vo_ctx* ctx, int which);
+float vo_kernel_time_ms(vo_ctx* ctx, int group, int* launches);
 
 /* --- detect_features / detect_keypoints_only -------------------------------
  * Replaces visual_odometry::detect_features (ref:src/feature_detector.cpp:12-18,

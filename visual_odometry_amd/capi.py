@@ -22,10 +22,12 @@ PAIR_DTYPE = np.dtype(
 
 EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
-    "vo_last_kernel_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
+    "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
     "vo_pipeline_pairs_dev", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
+
+T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac"]
 
 _lib = None
 
@@ -59,8 +61,8 @@ def load():
     lib.vo_ctx_stream.restype = vp
     lib.vo_sync.argtypes = [vp]
     lib.vo_set_timing.argtypes = [vp, i]
-    lib.vo_last_kernel_ms.argtypes = [vp, i]
-    lib.vo_last_kernel_ms.restype = f
+    lib.vo_kernel_time_ms.argtypes = [vp, i, C.POINTER(i)]
+    lib.vo_kernel_time_ms.restype = f
     lib.vo_orb_detect.argtypes = [vp, vp, i, i, i, i, vp, vp, i, C.POINTER(i)]
     lib.vo_orb_detect_batch_dev.argtypes = [vp, vp, i, i, i, i, sz, i, vp, vp, i, vp]
     lib.vo_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp, vp]
@@ -117,8 +119,11 @@ class Context:
     def set_timing(self, on=True):
         self.lib.vo_set_timing(self.h, int(on))
 
-    def last_kernel_ms(self, which):
-        return float(self.lib.vo_last_kernel_ms(self.h, which))
+    def kernel_time_ms(self, group):
+        """(mean ms per launch, launches) of a kernel group since timing was enabled."""
+        n = C.c_int()
+        ms = float(self.lib.vo_kernel_time_ms(self.h, group, C.byref(n)))
+        return ms, n.value
 
     # ---- host-buffer entry points ------------------------------------------------
     def orb_detect(self, img, max_features=2000, want_desc=True, cap=None):

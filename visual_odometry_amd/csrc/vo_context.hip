@@ -30,6 +30,28 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
     return VO_OK;
 }
 
+static hipEvent_t take_event(vo_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+void t_begin(vo_ctx* c, int group) {
+    if (!c->timing || c->ev_used > 60000) return;
+    hipEvent_t a = take_event(c), b = take_event(c);
+    if (!a || !b) return;
+    c->ev_pairs[group].emplace_back(a, b);
+    (void)hipEventRecord(a, c->stream);
+}
+
+void t_end(vo_ctx* c, int group) {
+    if (!c->timing || c->ev_pairs[group].empty()) return;
+    (void)hipEventRecord(c->ev_pairs[group].back().second, c->stream);
+}
+
 }  // namespace vo
 
 using namespace vo;
@@ -47,11 +69,6 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         delete c;
         return VO_ERR_HIP;
     }
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
-            return VO_ERR_HIP;
-        }
     *out = c;
     return VO_OK;
 }
@@ -68,7 +85,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
                       &c->p_kps,    &c->p_desc,   &c->p_cnt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
-    for (auto& e : c->ev)
+    for (auto& e : c->ev_pool)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -86,17 +103,26 @@ extern "C" int vo_sync(vo_ctx* c) {
 
 extern "C" int vo_set_timing(vo_ctx* c, int enabled) {
     if (!c) return VO_ERR_INVALID;
+    VO_HIP(c, hipStreamSynchronize(c->stream));
     c->timing = enabled != 0;
-    c->last_ms[0] = c->last_ms[1] = -1.f;
+    for (auto& v : c->ev_pairs) v.clear();
+    c->ev_used = 0;
     return VO_OK;
 }
 
-extern "C" float vo_last_kernel_ms(vo_ctx* c, int which) {
-    if (!c || which < 0 || which > 1 || !c->timing) return -1.f;
-    // events are recorded on the context's stream; wait for the later one
-    hipEvent_t a = c->ev[which * 2], b = c->ev[which * 2 + 1];
-    if (hipEventSynchronize(b) != hipSuccess) return -1.f;
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
-    return ms;
+extern "C" float vo_kernel_time_ms(vo_ctx* c, int group, int* launches) {
+    if (launches) *launches = 0;
+    if (!c || group < 0 || group >= VO_T_COUNT) return -1.f;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.f;
+    double sum = 0;
+    int n = 0;
+    for (auto& pr : c->ev_pairs[group]) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            sum += ms;
+            ++n;
+        }
+    }
+    if (launches) *launches = n;
+    return n ? (float)(sum / n) : -1.f;
 }

@@ -57,8 +57,9 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    float last_ms[2] = {-1.f, -1.f};
+    std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)
+    size_t ev_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[VO_T_COUNT];
 
     // detection workspace
     vo::Geom g{};
@@ -78,6 +79,9 @@ struct vo_ctx {
 namespace vo {
 
 int fail(vo_ctx* c, int code, const std::string& msg);
+// Records the begin / end event of one launch of kernel group `group` (no-ops unless timing is on).
+void t_begin(vo_ctx* c, int group);
+void t_end(vo_ctx* c, int group);
 int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
 
 #define VO_HIP(c, call)                                                                   \

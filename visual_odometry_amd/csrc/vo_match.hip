@@ -192,7 +192,7 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 1024) qpl >>= 1;
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
     hipStream_t s = c->stream;
-    if (c->timing) VO_HIP(c, hipEventRecord(c->ev[2], s));
+    t_begin(c, VO_T_KNN2);
     if (qpl == 4)
         hipLaunchKernelGGL(knn2_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);
@@ -202,7 +202,7 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     else
         hipLaunchKernelGGL(knn2_kernel<1>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);
-    if (c->timing) VO_HIP(c, hipEventRecord(c->ev[3], s));
+    t_end(c, VO_T_KNN2);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -212,8 +212,10 @@ int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
                  int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch) {
     if (batch <= 0) return VO_OK;
+    t_begin(c, VO_T_RATIO);
     hipLaunchKernelGGL(ratio_kernel, dim3(batch), dim3(256), 0, c->stream, d_idx2, d_dist2, d_nq, cnt_stride, nq_max, ratio, d_kp1,
                        d_kp2, kp_stride, d_qidx, d_tidx, d_dist, d_p1, d_p2, d_nmatch);
+    t_end(c, VO_T_RATIO);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }

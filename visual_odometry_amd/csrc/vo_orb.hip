@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void select_kernel(Geom g, SmallTabs tabs, con
     __shared__ float resp[CAP];
     __shared__ uint32_t srt[CAP];
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_n, s_thr, s_scan[9];
+    __shared__ uint32_t s_n, s_thr;
     __shared__ int s_umax[16];
 
     const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
@@ -708,17 +708,20 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     const uint8_t* pyr = (const uint8_t*)c->pyr.p;
     VO_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, (size_t)N * kLevels * 4, s));
     VO_HIP(c, hipMemsetAsync(c->flags.p, 0, 256, s));
+    t_begin(c, VO_T_RESIZE);
     for (int l = 1; l < kLevels; ++l) {
         dim3 grid((g.L[l].w + 255) / 256, (g.L[l].h + 3) / 4, N);
         hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, s, g, l, d_imgs, (uint8_t*)c->pyr.p,
                            (const uint32_t*)c->tab.p);
     }
+    t_end(c, VO_T_RESIZE);
     if (g.fast_tiles > 0) {
-        if (c->timing) VO_HIP(c, hipEventRecord(c->ev[0], s));
+        t_begin(c, VO_T_FAST);
         hipLaunchKernelGGL(fast_kernel, dim3(g.fast_tiles, N), dim3(256), 0, s, g, d_imgs, pyr, (uint32_t*)c->cand.p,
                            (uint32_t*)c->cand_cnt.p);
-        if (c->timing) VO_HIP(c, hipEventRecord(c->ev[1], s));
+        t_end(c, VO_T_FAST);
     }
+    t_begin(c, VO_T_SELECT);
 #define VO_SELECT(CAPV)                                                                                              \
     hipLaunchKernelGGL(select_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g, tabs, d_imgs, pyr,                \
                        (const uint32_t*)c->cand.p, (const uint32_t*)c->cand_cnt.p, (uint16_t*)c->kp_x.p,            \
@@ -728,15 +731,21 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     else if (g.sel_cap == 4096) VO_SELECT(4096);
     else VO_SELECT(8192);
 #undef VO_SELECT
-    if (d_desc)
+    t_end(c, VO_T_SELECT);
+    if (d_desc) {
+        t_begin(c, VO_T_BLUR);
         hipLaunchKernelGGL(blur_kernel, dim3(g.blur_tiles, N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
                            (uint8_t*)c->blur.p);
+        t_end(c, VO_T_BLUR);
+    }
+    t_begin(c, VO_T_DESCRIBE);
     int max_kp = 0;
     for (int l = 0; l < kLevels; ++l) max_kp = std::max(max_kp, g.L[l].kp_cap);
     hipLaunchKernelGGL(describe_kernel, dim3((max_kp + 3) / 4, kLevels, N), dim3(256), 0, s, g,
                        (const uint8_t*)c->blur.p, (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p,
                        (const float*)c->kp_resp.p, (const float*)c->kp_angle.p, (const uint32_t*)c->kp_cnt.p, d_kps,
                        d_desc, cap, d_counts, (uint32_t*)c->flags.p);
+    t_end(c, VO_T_DESCRIBE);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -789,10 +798,6 @@ extern "C" int vo_orb_detect(vo_ctx* c, const uint8_t* img, int rows, int cols, 
         if (desc_out)
             VO_HIP(c, hipMemcpyAsync(desc_out, c->st_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
         VO_HIP(c, hipStreamSynchronize(c->stream));
-    }
-    if (c->timing && c->g.fast_tiles > 0) {
-        float ms = -1.f;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->last_ms[0] = ms;
     }
     *n_out = n;
     return VO_OK;

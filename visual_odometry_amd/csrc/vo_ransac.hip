@@ -972,6 +972,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int32_t* nmodels = (int32_t*)c->r_nmodels.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
 
+    t_begin(c, VO_T_RANSAC);
     if (n_max > 0)
         hipLaunchKernelGGL(normalize_kernel, dim3((n_max + 255) / 256, batch), dim3(256), 0, s, d_p1, d_p2, d_n, n_max, P,
                            m);
@@ -995,6 +996,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     }
     hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(256), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
                        d_good);
+    t_end(c, VO_T_RANSAC);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
