@@ -7,7 +7,7 @@ HDRS := $(CSRC)/vo_internal.h $(CSRC)/orb_pattern.inc include/vo_hip.h
 OBJS := $(SRCS:.hip=.o)
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 
-all: visual_odometry_amd/libvo_hip.so
+all: visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin
 
 %.o: %.hip $(HDRS)
 	$(HIPCC) $(FLAGS) -c $< -o $@
@@ -15,10 +15,18 @@ all: visual_odometry_amd/libvo_hip.so
 visual_odometry_amd/libvo_hip.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# C++20 drop-in layer (the reference's three interfaces over the C ABI) and its test binary
+CXX ?= g++
+visual_odometry_amd/libvisual_odometry_hip.so: $(CSRC)/host/vo_cpp_api.cpp include/visual_odometry/*.hpp include/visual_odometry/compat/*.hpp include/vo_hip.h visual_odometry_amd/libvo_hip.so
+	$(CXX) -std=c++20 -O2 -fPIC -shared -Iinclude -o $@ $(CSRC)/host/vo_cpp_api.cpp -Lvisual_odometry_amd -lvo_hip -Wl,-rpath,'$$ORIGIN'
+
+tests/cpp/test_dropin: tests/cpp/test_dropin.cpp visual_odometry_amd/libvisual_odometry_hip.so
+	$(CXX) -std=c++20 -O2 -Iinclude -o $@ tests/cpp/test_dropin.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN/../../visual_odometry_amd' -Wl,-rpath-link,visual_odometry_amd
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) visual_odometry_amd/libvo_hip.so
+	rm -f $(OBJS) visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin
 
 .PHONY: all oracle clean

@@ -1,0 +1,62 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU partitioning: query-row sharding of the
+Hamming match with one gather, and block sharding of frame pairs."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visual_odometry_amd import sharding, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, nt, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    q = synth.descriptors(7, nq, dup_fraction=0.1)
+    t = synth.descriptors(8, nt, dup_fraction=0.1)
+    b, e = sharding.block_range(nq, rank, world)
+    idx, d = O.knn2(q[b:e], t)                       # the rank's shard of the distance matrix
+    both = torch.from_numpy(np.concatenate([idx, d], 1))
+    full = sharding.gather_rows(both, nq, dst=0)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_row_sharding_gathers_the_full_table(tmp_path, oracle):
+    nq, nt, world = 1001, 700, 2                      # odd count: unequal shards
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(world, _free_port(), nq, nt, out), nprocs=world, join=True)
+    got = np.load(out)
+    idx, d = oracle.knn2(synth.descriptors(7, nq, dup_fraction=0.1), synth.descriptors(8, nt, dup_fraction=0.1))
+    assert np.array_equal(got[:, :2], idx) and np.array_equal(got[:, 2:], d)
+
+
+def test_block_range_partitions_everything():
+    for n in (0, 1, 7, 64, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.block_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_rows_without_process_group_is_identity():
+    x = torch.arange(12).reshape(6, 2)
+    assert sharding.gather_rows(x, 6) is x
