@@ -140,6 +140,19 @@ __host__ __device__ __forceinline__ void mul_ql_row(const double* q, const doubl
         }
 }
 
+// row[20] (registers) += s * q[10] (x) l[4]
+__host__ __device__ __forceinline__ void mul_ql_reg(const double* q, const double* l, double s, double* row) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            constexpr int CI[10][4] = {{0, 2, 4, 5},    {2, 3, 8, 9},     {4, 8, 10, 11},   {5, 9, 11, 12},
+                                       {3, 1, 6, 7},    {8, 6, 13, 14},   {9, 7, 14, 15},   {10, 13, 16, 17},
+                                       {11, 14, 17, 18}, {12, 15, 18, 19}};
+            row[CI[i][j]] += s * (q[i] * l[j]);
+        }
+}
+
 // j-th derivative of the polynomial c (degree n) at x; dc[j] holds its coefficients.
 __host__ __device__ __forceinline__ double poly_eval(const double* d, int deg, double x) {
     double v = d[deg];
@@ -231,6 +244,107 @@ __host__ __device__ int real_roots(const double* c, double* roots) {
     return np;
 }
 
+// ---- degree-10 fast path of real_roots(): the same derivative-interlacing scheme with
+// every polynomial held in registers (statically unrolled per degree); only the two
+// short root lists live in this lane's LDS column.
+__host__ __device__ constexpr double falling(int m, int j) {   // m! / (m-j)!
+    double r = 1.0;
+    for (int i = 0; i < j; ++i) r *= (double)(m - i);
+    return r;
+}
+
+template <int DEG>
+__host__ __device__ __forceinline__ double horner(const double (&d)[DEG + 1], double x) {
+    double v = d[DEG];
+#pragma unroll
+    for (int i = DEG - 1; i >= 0; --i) v = v * x + d[i];
+    return v;
+}
+
+// Roots of the (10-DEG)-th derivative of c (degree DEG) given the np roots of the next
+// derivative in sP (ascending).  Writes them ascending to sC, returns their number.
+template <int DEG>
+__host__ __device__ __forceinline__ int roots_level(const double* c, const double* sP, int np, double* sC) {
+    constexpr int J = 10 - DEG;
+    double d[DEG + 1], dd[DEG];
+#pragma unroll
+    for (int i = 0; i <= DEG; ++i) d[i] = c[i + J] * falling(i + J, J);
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
+    double R = 0;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i] / d[DEG]));
+    R += 1.0;
+    int nc = 0;
+    double last = 0;   // last root written (valid when nc > 0)
+    double a = -R, fa = horner<DEG>(d, a);
+    for (int k = 0; k <= np; ++k) {
+        double b = k < np ? fmin(fmax(sP[k * ST], -R), R) : R;
+        double fb = horner<DEG>(d, b);
+        if (b > a) {
+            if (fa == 0.0) {
+                if (nc == 0 || last != a) { sC[nc * ST] = a; last = a; ++nc; }
+            } else if ((fa < 0) != (fb < 0) && fb != 0.0) {
+                double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
+                double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold;
+                double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
+                for (int it = 0; it < 100; ++it) {
+                    if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+                        dxold = dx;
+                        dx = 0.5 * (xh - xl);
+                        x = xl + dx;
+                    } else {
+                        dxold = dx;
+                        dx = f / df;
+                        x -= dx;
+                    }
+                    if (fabs(dx) <= 4.0 * DBL_EPSILON * fmax(1.0, fabs(x))) break;
+                    f = horner<DEG>(d, x);
+                    df = horner<DEG - 1>(dd, x);
+                    if (f == 0.0) break;
+                    if (f < 0.0) xl = x; else xh = x;
+                }
+                bool dup = DEG == 10 && nc > 0 && fabs(x - last) <= 1e-7 * fmax(1.0, fabs(x));
+                if (nc < 10 && !dup) { sC[nc * ST] = x; last = x; ++nc; }
+            }
+        }
+        if (DEG == 10 && k < np && fb != 0.0) {
+            double ab = fabs(b);
+            double mag = fabs(d[DEG]);
+#pragma unroll
+            for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
+            bool dup = nc > 0 && fabs(b - last) <= 1e-7 * fmax(1.0, ab);
+            if (fabs(fb) <= 1e-6 * mag && !dup && nc < 10) { sC[nc * ST] = b; last = b; ++nc; }
+        }
+        if (b > a) {
+            a = b;
+            fa = fb;
+        }
+    }
+    if (fa == 0.0 && nc < 10 && (nc == 0 || last != a)) { sC[nc * ST] = a; ++nc; }
+    return nc;
+}
+
+// c: degree-10 polynomial with a non-negligible leading coefficient.  Roots (ascending)
+// end up in sW[0..n) (stride ST); sW needs 20 slots.
+__host__ __device__ __forceinline__ int real_roots10(const double* c, double* sW) {
+    double* A = sW;
+    double* B = sW + 10 * ST;
+    A[0] = -(c[9] * falling(9, 9)) / (c[10] * falling(10, 9));   // root of the 9th derivative
+    int n = 1;
+    n = roots_level<2>(c, A, n, B);
+    n = roots_level<3>(c, B, n, A);
+    n = roots_level<4>(c, A, n, B);
+    n = roots_level<5>(c, B, n, A);
+    n = roots_level<6>(c, A, n, B);
+    n = roots_level<7>(c, B, n, A);
+    n = roots_level<8>(c, A, n, B);
+    n = roots_level<9>(c, B, n, A);
+    n = roots_level<10>(c, A, n, B);
+    for (int k = 0; k < n; ++k) A[k * ST] = B[k * ST];
+    return n;
+}
+
 // The ten cubic constraints on an essential matrix, f(E) = [det E ;
 // 2 E E^T E - trace(E E^T) E], and (dir != nullptr) their derivative along D.
 __host__ __device__ __forceinline__ void ess_constraints(const double* E, double* f) {
@@ -314,6 +428,8 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
         double d1 = (n00 * (g1 * n22 - n12 * g2) - g0 * c01 + n02 * (n01 * g2 - g1 * n02)) * inv;
         double d2 = (n00 * (n11 * g2 - g1 * n12) - n01 * (n01 * g2 - g1 * n02) + g0 * c02) * inv;
         x -= d0; y -= d1; z -= d2;
+        // converged: one more pass only rebuilds E from the final (x,y,z)
+        if (fmax(fabs(d0), fmax(fabs(d1), fabs(d2))) <= 1e-14 * fmax(1.0, fmax(fabs(x), fmax(fabs(y), fabs(z))))) it = 3;
     }
     double nrm = 0;
 #pragma unroll
@@ -402,28 +518,31 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     for (int rc = 0; rc < 9; ++rc)
 #pragma unroll
         for (int t = 0; t < 4; ++t) El[rc][t] = EE[t][rc];
-#pragma unroll 1
-    for (int i = 0; i < 200; ++i) sA[i * ST] = 0.0;
+#define A_(r, c) sA[((r) * 20 + (c)) * ST]
     {
         // det(E) = 0
-        double m0[10] = {0}, m1[10] = {0}, m2[10] = {0};
+        double m0[10] = {0}, m1[10] = {0}, m2[10] = {0}, row[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) row[i] = 0;
         mul_ll(El[4], El[8], 1.0, m0); mul_ll(El[5], El[7], -1.0, m0);
         mul_ll(El[3], El[8], 1.0, m1); mul_ll(El[5], El[6], -1.0, m1);
         mul_ll(El[3], El[7], 1.0, m2); mul_ll(El[4], El[6], -1.0, m2);
-        mul_ql_row(m0, El[0], 1.0, sA);
-        mul_ql_row(m1, El[1], -1.0, sA);
-        mul_ql_row(m2, El[2], 1.0, sA);
+        mul_ql_reg(m0, El[0], 1.0, row);
+        mul_ql_reg(m1, El[1], -1.0, row);
+        mul_ql_reg(m2, El[2], 1.0, row);
+#pragma unroll
+        for (int i = 0; i < 20; ++i) A_(0, i) = row[i];
     }
     {
         // (E E^T - trace(E E^T)/2 I) E = 0
         double L[6][10];   // symmetric: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
         const int sr[6] = {0, 0, 0, 1, 1, 2}, sc[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int q = 0; q < 6; ++q) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) L[s][i] = 0;
+            for (int i = 0; i < 10; ++i) L[q][i] = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) mul_ll(El[sr[s] * 3 + k], El[sc[s] * 3 + k], 1.0, L[s]);
+            for (int k = 0; k < 3; ++k) mul_ll(El[sr[q] * 3 + k], El[sc[q] * 3 + k], 1.0, L[q]);
         }
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
@@ -435,34 +554,46 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                double* row = sA + (size_t)(1 + r * 3 + c) * 20 * ST;
+                double row[20];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) mul_ql_row(L[sym[r][k]], El[k * 3 + c], 1.0, row);
+                for (int i = 0; i < 20; ++i) row[i] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mul_ql_reg(L[sym[r][k]], El[k * 3 + c], 1.0, row);
+#pragma unroll
+                for (int i = 0; i < 20; ++i) A_(1 + r * 3 + c, i) = row[i];
             }
     }
-    // ---- Gauss-Jordan on the first ten columns (partial pivoting)
-#define A_(r, c) sA[((r) * 20 + (c)) * ST]
+    // ---- Gauss-Jordan on the first ten columns (partial pivoting), statically unrolled.
+    // Only rows 4..9 are needed fully reduced, so rows 0..3 are never eliminated upwards.
+#pragma unroll
     for (int k = 0; k < 10; ++k) {
         int p = k;
         double best = fabs(A_(k, k));
+#pragma unroll
         for (int r = k + 1; r < 10; ++r) {
             double v = fabs(A_(r, k));
             if (v > best) { best = v; p = r; }
         }
         if (!(best > 1e-300)) return 0;
-        if (p != k)
-            for (int c = k; c < 20; ++c) {
-                double t = A_(k, c);
-                A_(k, c) = A_(p, c);
-                A_(p, c) = t;
-            }
-        double inv = 1.0 / A_(k, k);
-        for (int c = k; c < 20; ++c) A_(k, c) *= inv;
+        double pr[20];
+#pragma unroll
+        for (int c = k; c < 20; ++c) pr[c] = sA[(p * 20 + c) * ST];
+        if (p != k) {
+#pragma unroll
+            for (int c = k; c < 20; ++c) sA[(p * 20 + c) * ST] = A_(k, c);
+        }
+        double inv = 1.0 / pr[k];
+#pragma unroll
+        for (int c = k; c < 20; ++c) {
+            pr[c] *= inv;
+            A_(k, c) = pr[c];
+        }
+#pragma unroll
         for (int r = 0; r < 10; ++r) {
-            if (r == k) continue;
+            if (r == k || (r < k && r < 4)) continue;
             double f = A_(r, k);
-            if (f == 0.0) continue;
-            for (int c = k; c < 20; ++c) A_(r, c) -= f * A_(k, c);
+#pragma unroll
+            for (int c = k + 1; c < 20; ++c) A_(r, c) -= f * pr[c];
         }
     }
     // rows 4..9 <-> x^2 z, x^2, y^2 z, y^2, x y z, x y; columns 10..19 <->
@@ -523,11 +654,24 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
                     if (i + j <= 10) cf[i + j] += sgn[p] * (t01[i] * f[2][perm[p][2]][j]);
         }
     }
-    double roots[10];
-    int nr = real_roots(cf, roots);
+    // the elimination matrix is no longer needed: its LDS column becomes the root lists
+    int nr;
+    {
+        double cmax = 0;
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
+        if (!(cmax > 0) || !(cmax < DBL_MAX)) return 0;
+        if (fabs(cf[10]) > 1e-14 * cmax) {
+            nr = real_roots10(cf, sA);
+        } else {   // degree-deficient polynomial (rare): generic path
+            double roots[10];
+            nr = real_roots(cf, roots);
+            for (int k = 0; k < nr; ++k) sA[k * ST] = roots[k];
+        }
+    }
     int count = 0;
     for (int ri = 0; ri < nr && count < kMaxModels; ++ri) {
-        double z1 = roots[ri], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double z1 = sA[ri * ST], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[3][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -936,7 +1080,7 @@ __global__ __launch_bounds__(ST) void five_point_debug_kernel(const double* __re
 
 static int round_size(int round, int fixed) {
     if (fixed > 0) return 512;
-    static const int sz[] = {32, 96, 128, 256, 488};
+    static const int sz[] = {64, 64, 128, 256, 488};
     return round < 5 ? sz[round] : 0;
 }
 
