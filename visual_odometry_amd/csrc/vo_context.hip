@@ -78,7 +78,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
-                      &c->kp_resp,  &c->kp_angle, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
+                      &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->m_top2,   &c->m_qidx,
                       &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
                       &c->r_models, &c->r_nmodels, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_res,

@@ -65,7 +65,7 @@ struct vo_ctx {
     vo::Geom g{};
     bool geom_valid = false;
     std::vector<uint32_t> h_tab;   // resize tables (host copy)
-    vo::DevBuf tab, pyr, blur, cand, cand_cnt, kp_x, kp_y, kp_resp, kp_angle, kp_cnt, flags;
+    vo::DevBuf tab, pyr, blur, cand, cand_cnt, kp_x, kp_y, kp_resp, kp_cnt, flags, sel_keys, sel_resp, sel_cnt;
     const uint8_t* last_imgs = nullptr;
     // staging for the host-buffer entry points
     vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist;

@@ -265,24 +265,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__device__ __forceinline__ float ic_angle_at(const uint8_t* img, int pitch, int x0, int y0, const int* umax) {
-    const uint8_t* center = img + (size_t)y0 * pitch + x0;
-    int m01 = 0, m10 = 0;
-    for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * center[u];
-    for (int v = 1; v <= kHalfPatch; ++v) {
-        int vsum = 0, d = umax[v];
-        const uint8_t* rp = center + v * pitch;
-        const uint8_t* rm = center - v * pitch;
-        for (int u = -d; u <= d; ++u) {
-            int vp = rp[u], vm = rm[u];
-            vsum += (vp - vm);
-            m10 += u * (vp + vm);
-        }
-        m01 += v * vsum;
-    }
-    return fast_atan2_deg((float)m01, (float)m10);
-}
-
 template <typename T>
 __device__ void bitonic_sort_asc(T* s, int P, int tid, int nt) {
     for (int k = 2; k <= P; k <<= 1)
@@ -302,23 +284,22 @@ __device__ void bitonic_sort_asc(T* s, int P, int tid, int nt) {
         }
 }
 
-// One workgroup per (level, image): retainBest(2n) on the FAST score, raster
-// order, Harris response, retainBest(n) on it, angle.  "retainBest(n)" keeps
-// every element whose value is >= the n-th largest (ties survive).
+// Selection runs as three kernels so that the per-candidate image reads (Harris) are
+// spread over the whole batch instead of being serialised inside one workgroup:
+//   select_a: per (level, image) workgroup - retainBest(2n) on the FAST score via a
+//             256-bin LDS histogram, then raster order by an LDS bitonic sort;
+//   harris:   one lane per surviving candidate, batch-wide;
+//   select_b: per (level, image) workgroup - retainBest(n) on the Harris response,
+//             ordered compaction.
+// "retainBest(n)" keeps every element whose value is >= the n-th largest (ties survive).
 template <int CAP>
-__global__ __launch_bounds__(512) void select_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
-                                                     const uint8_t* __restrict__ pyr,
-                                                     const uint32_t* __restrict__ cand,
-                                                     const uint32_t* __restrict__ cand_cnt,
-                                                     uint16_t* __restrict__ kp_x, uint16_t* __restrict__ kp_y,
-                                                     float* __restrict__ kp_resp, float* __restrict__ kp_angle,
-                                                     uint32_t* __restrict__ kp_cnt, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* __restrict__ cand,
+                                                       const uint32_t* __restrict__ cand_cnt,
+                                                       uint32_t* __restrict__ sel_keys, uint32_t* __restrict__ sel_cnt,
+                                                       uint32_t* __restrict__ flags) {
     __shared__ uint32_t keys[CAP];
-    __shared__ float resp[CAP];
-    __shared__ uint32_t srt[CAP];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_n, s_thr;
-    __shared__ int s_umax[16];
 
     const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     constexpr int NT = 512;
@@ -327,26 +308,36 @@ __global__ __launch_bounds__(512) void select_kernel(Geom g, SmallTabs tabs, con
     const uint32_t* cl = cand + (size_t)img * g.cand_stride + L.cand_off;
     const int quota = L.quota;
     if (tid < 256) hist[tid] = 0;
-    if (tid < 16) s_umax[tid] = tabs.umax[tid];
     if (tid == 0) s_n = 0;
     __syncthreads();
     if (total == 0 || quota == 0) {
-        if (tid == 0) kp_cnt[img * kLevels + l] = 0;
+        if (tid == 0) sel_cnt[img * kLevels + l] = 0;
         return;
     }
-    // --- retainBest(2*quota) by FAST score
     uint32_t thr_score = 0;
     if (total > (uint32_t)(2 * quota)) {
         for (uint32_t i = tid; i < total; i += NT) atomicAdd(&hist[cl[i] >> 24], 1u);
         __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = 0;
-            int s = 255;
-            for (; s > 0; --s) {
-                acc += hist[s];
-                if (acc >= (uint32_t)(2 * quota)) break;
+        if (tid < 64) {
+            // suffix sums of the histogram, four bins per lane, then the largest score s
+            // with count(score >= s) >= 2*quota
+            uint32_t h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+            uint32_t mine = h0 + h1 + h2 + h3, suf = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = __shfl_down(suf, o);
+                if (tid + o < 64) suf += v;
             }
-            s_thr = (uint32_t)s;
+            uint32_t above = suf - mine;   // bins of higher lanes
+            uint32_t need = (uint32_t)(2 * quota);
+            int s = -1;
+            if (above + h3 >= need) s = tid * 4 + 3;
+            else if (above + h3 + h2 >= need) s = tid * 4 + 2;
+            else if (above + h3 + h2 + h1 >= need) s = tid * 4 + 1;
+            else if (suf >= need) s = tid * 4;
+            unsigned long long m = __ballot(s >= 0);
+            int top = 63 - __builtin_clzll(m);   // total > 2*quota guarantees m != 0
+            if (tid == top) s_thr = (uint32_t)s;
         }
         __syncthreads();
         thr_score = s_thr;
@@ -369,82 +360,118 @@ __global__ __launch_bounds__(512) void select_kernel(Geom g, SmallTabs tabs, con
     for (int i = M + tid; i < P; i += NT) keys[i] = 0xFFFFFFFFu;
     __syncthreads();
     bitonic_sort_asc(keys, P, tid, NT);   // raster order: key = y << 12 | x
+    uint32_t* out = sel_keys + ((size_t)img * kLevels + l) * CAP;
+    for (int i = tid; i < (int)M; i += NT) out[i] = keys[i];
+    if (tid == 0) sel_cnt[img * kLevels + l] = M;
+}
 
+__global__ __launch_bounds__(256) void harris_kernel(Geom g, int cap, const uint8_t* __restrict__ in,
+                                                     const uint8_t* __restrict__ pyr,
+                                                     const uint32_t* __restrict__ sel_keys,
+                                                     const uint32_t* __restrict__ sel_cnt, float* __restrict__ sel_resp) {
+    int l = blockIdx.y, img = blockIdx.z;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int)sel_cnt[img * kLevels + l]) return;
+    size_t o = ((size_t)img * kLevels + l) * cap + i;
+    uint32_t k = sel_keys[o];
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
-    for (int i = tid; i < (int)M; i += NT) {
-        uint32_t k = keys[i];
-        resp[i] = harris_at(base, pitch, k & 0xFFF, k >> 12);
+    sel_resp[o] = harris_at(base, pitch, k & 0xFFF, k >> 12);
+}
+
+template <int CAP>
+__global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* __restrict__ sel_keys,
+                                                       const uint32_t* __restrict__ sel_cnt,
+                                                       const float* __restrict__ sel_resp, uint16_t* __restrict__ kp_x,
+                                                       uint16_t* __restrict__ kp_y, float* __restrict__ kp_resp,
+                                                       uint32_t* __restrict__ kp_cnt, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t inv[CAP];    // ~sortable(response): ascending == best first
+    __shared__ uint32_t srt[CAP];
+    __shared__ uint32_t wsum[8];
+    __shared__ uint32_t s_tot;
+    const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = 512;
+    const LevelGeom& L = g.L[l];
+    const int quota = L.quota;
+    const int M = (int)sel_cnt[img * kLevels + l];
+    if (M == 0) {
+        if (tid == 0) kp_cnt[img * kLevels + l] = 0;
+        return;
+    }
+    const size_t ib = ((size_t)img * kLevels + l) * CAP;
+    int P = 1;
+    while (P < M) P <<= 1;
+    for (int i = tid; i < P; i += NT) {
+        uint32_t v = i < M ? ~f2sortable(sel_resp[ib + i]) : 0xFFFFFFFFu;
+        inv[i] = v;
+        srt[i] = v;
     }
     __syncthreads();
-    // --- retainBest(quota) by Harris response
-    uint32_t inv_thr = 0xFFFFFFFFu;   // keep iff ~sortable(resp) <= inv_thr
-    if (M > (uint32_t)quota) {
-        for (int i = tid; i < P; i += NT) srt[i] = i < (int)M ? ~f2sortable(resp[i]) : 0xFFFFFFFFu;
-        __syncthreads();
+    uint32_t inv_thr = 0xFFFFFFFFu;   // keep iff inv <= inv_thr
+    if (M > quota) {
         bitonic_sort_asc(srt, P, tid, NT);
         inv_thr = srt[quota - 1];
         __syncthreads();
     }
-    // ordered compaction: per-thread contiguous chunk, then a scan of chunk totals
-    int chunk = ((int)M + NT - 1) / NT;
-    int beg = min(tid * chunk, (int)M), end = min(beg + chunk, (int)M);
-    int mine = 0;
-    for (int i = beg; i < end; ++i) mine += (~f2sortable(resp[i]) <= inv_thr);
-    srt[tid] = mine;   // srt is free again
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (int i = 0; i < NT; ++i) {
-            uint32_t v = srt[i];
-            srt[i] = acc;
-            acc += v;
-        }
-        s_n = acc;
-    }
-    __syncthreads();
-    uint32_t F = s_n;
-    uint32_t pos = srt[tid];
-    __syncthreads();
-    if (F > (uint32_t)L.kp_cap) {
-        if (tid == 0) atomicOr(flags, 2u);
-        F = L.kp_cap;
-    }
-    // reuse srt as the compacted index list
-    for (int i = beg; i < end; ++i)
-        if (~f2sortable(resp[i]) <= inv_thr) {
-            if (pos < F) srt[pos] = i;
-            ++pos;
-        }
-    __syncthreads();
+    // ordered compaction: ballot prefix inside a wave, wave totals through LDS
+    uint32_t base_out = 0;
+    uint32_t F_cap = (uint32_t)L.kp_cap;
     size_t ob = (size_t)img * g.kp_stride + L.kp_off;
-    for (int j = tid; j < (int)F; j += NT) {
-        int i = srt[j];
-        uint32_t k = keys[i];
-        int x = k & 0xFFF, y = k >> 12;
-        kp_x[ob + j] = (uint16_t)x;
-        kp_y[ob + j] = (uint16_t)y;
-        kp_resp[ob + j] = resp[i];
-        kp_angle[ob + j] = ic_angle_at(base, pitch, x, y, s_umax);
+    for (int i0 = 0; i0 < M; i0 += NT) {
+        int i = i0 + tid;
+        bool keep = i < M && inv[i] <= inv_thr;
+        unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = base_out;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < F_cap) {
+                uint32_t k = sel_keys[ib + i];
+                kp_x[ob + pos] = (uint16_t)(k & 0xFFF);
+                kp_y[ob + pos] = (uint16_t)(k >> 12);
+                kp_resp[ob + pos] = sel_resp[ib + i];
+            }
+        }
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < 8; ++w) t += wsum[w];
+            s_tot = t;
+        }
+        __syncthreads();
+        base_out += s_tot;
+        __syncthreads();
     }
-    if (tid == 0) kp_cnt[img * kLevels + l] = F;
+    if (tid == 0) {
+        if (base_out > F_cap) {
+            atomicOr(flags, 2u);
+            base_out = F_cap;
+        }
+        kp_cnt[img * kLevels + l] = base_out;
+    }
 }
 
 // ------------------------------------------------------------------ blur
 // 7x7 separable fixed-point blur (taps sum to 257, 8 fractional bits each),
 // BORDER_REFLECT_101.  Column stage rounds sum/65536 half-to-even for columns
 // below (w & ~3) and half-up for the rest, saturating to 255.
-constexpr int BT_W = 64, BT_H = 16;
+constexpr int BT_W = 64, BT_H = 32;
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
     return p;
 }
 
+// Tile = 64 x 32 outputs.  The pixel tile (3-row / 4-column halo, dword-aligned origin)
+// is staged in LDS with dword loads (byte loads with reflection on tiles that touch the
+// border); the row pass produces four outputs per lane with two v_dot4_u32_u8 each on
+// byte-aligned windows (v_alignbyte), the column pass reads four u16 row sums per ds_read.
 __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t px[(BT_H + 6) * (BT_W + 8)];
-    __shared__ uint16_t hs[(BT_H + 6) * BT_W];
+    constexpr int PW = BT_W + 8, PH = BT_H + 6;          // LDS column 0 <-> image column x0 - 4
+    __shared__ __attribute__((aligned(16))) uint8_t px[PH * PW];
+    __shared__ __attribute__((aligned(16))) uint16_t hs[PH * BT_W];
     int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     int l = 0;
 #pragma unroll
@@ -457,103 +484,201 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     int x0 = (tl % L.blur_tx) * BT_W, y0 = (tl / L.blur_tx) * BT_H;
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
-    constexpr int PW = BT_W + 8;
-    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
-        int y = reflect101(y0 - 3 + r, L.h), x = reflect101(min(x0 - 3 + c, L.w + 2), L.w);
-        px[r * PW + c] = base[(size_t)y * pitch + x];
+    bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
+    bool interior = aligned && x0 >= 4 && x0 + BT_W + 4 <= L.w && y0 >= 3 && y0 + BT_H + 3 <= L.h;
+    if (interior) {
+        for (int i = tid; i < PH * (PW / 4); i += 256) {
+            int r = i / (PW / 4), c = i - r * (PW / 4);
+            uint32_t v = *reinterpret_cast<const uint32_t*>(base + (size_t)(y0 - 3 + r) * pitch + (x0 - 4) + 4 * c);
+            *reinterpret_cast<uint32_t*>(&px[r * PW + 4 * c]) = v;
+        }
+    } else {
+        for (int i = tid; i < PH * PW; i += 256) {
+            int r = i / PW, c = i - r * PW;
+            int y = reflect101(y0 - 3 + r, L.h), x = reflect101(min(x0 - 4 + c, L.w + 3), L.w);
+            px[i] = base[(size_t)y * pitch + x];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
-        int r = i / BT_W, c = i - r * BT_W;
-        const uint8_t* p = &px[r * PW + c];
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s += tabs.taps[k] * p[k];
-        hs[i] = (uint16_t)s;
+    const uint32_t t0123 = (uint32_t)tabs.taps[0] | ((uint32_t)tabs.taps[1] << 8) | ((uint32_t)tabs.taps[2] << 16) |
+                           ((uint32_t)tabs.taps[3] << 24);
+    const uint32_t t456 = (uint32_t)tabs.taps[4] | ((uint32_t)tabs.taps[5] << 8) | ((uint32_t)tabs.taps[6] << 16);
+    // row pass: outputs x = 4*gx + j read LDS columns 4*gx + 1 + j .. + 7 + j
+    for (int i = tid; i < PH * (BT_W / 4); i += 256) {
+        int r = i / (BT_W / 4), gx = i - r * (BT_W / 4);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&px[r * PW + 4 * gx]);
+        uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), b0 = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        uint32_t a1 = __builtin_amdgcn_alignbyte(w1, w0, 2), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+        uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), b2 = __builtin_amdgcn_alignbyte(w2, w1, 3);
+        uint32_t s0 = __builtin_amdgcn_udot4(a0, t0123, __builtin_amdgcn_udot4(b0, t456, 0u, false), false);
+        uint32_t s1 = __builtin_amdgcn_udot4(a1, t0123, __builtin_amdgcn_udot4(b1, t456, 0u, false), false);
+        uint32_t s2 = __builtin_amdgcn_udot4(a2, t0123, __builtin_amdgcn_udot4(b2, t456, 0u, false), false);
+        uint32_t s3 = __builtin_amdgcn_udot4(w1, t0123, __builtin_amdgcn_udot4(w2, t456, 0u, false), false);
+        uint2 o;
+        o.x = s0 | (s1 << 16);
+        o.y = s2 | (s3 << 16);
+        *reinterpret_cast<uint2*>(&hs[r * BT_W + 4 * gx]) = o;
     }
     __syncthreads();
     int vec_end = L.w & ~3;
     uint8_t* out = blur + (size_t)img * g.blk_stride + L.off;   // blur block uses the same offsets
-    for (int i = tid; i < BT_H * BT_W; i += 256) {
-        int r = i / BT_W, c = i - r * BT_W;
-        int X = x0 + c, Y = y0 + r;
+    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
+        int r = i / (BT_W / 4), gx = i - r * (BT_W / 4);
+        int X = x0 + 4 * gx, Y = y0 + r;
         if (X >= L.w || Y >= L.h) continue;
-        uint32_t s = 0;
+        uint32_t s[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s += (uint32_t)tabs.taps[k] * hs[(r + k) * BT_W + c];
-        uint32_t q = s >> 16, rem = s & 0xFFFFu;
-        uint32_t v = X < vec_end ? q + ((rem > 32768u) || (rem == 32768u && (q & 1u))) : (s + 32768u) >> 16;
-        out[(size_t)Y * L.pitch + X] = (uint8_t)min(v, 255u);
+        for (int k = 0; k < 7; ++k) {
+            uint2 h = *reinterpret_cast<const uint2*>(&hs[(r + k) * BT_W + 4 * gx]);
+            uint32_t t = (uint32_t)tabs.taps[k];
+            s[0] += t * (h.x & 0xFFFFu);
+            s[1] += t * (h.x >> 16);
+            s[2] += t * (h.y & 0xFFFFu);
+            s[3] += t * (h.y >> 16);
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t q = s[j] >> 16, rem = s[j] & 0xFFFFu;
+            uint32_t v = (X + j) < vec_end ? q + ((rem > 32768u) || (rem == 32768u && (q & 1u))) : (s[j] + 32768u) >> 16;
+            packed |= min(v, 255u) << (8 * j);
+        }
+        // the row pitch is a multiple of 64, so the dword store stays inside the row even when
+        // the level width is not a multiple of 4 (the surplus bytes are never read as pixels)
+        *reinterpret_cast<uint32_t*>(out + (size_t)Y * L.pitch + X) = packed;
     }
 }
 
 // ------------------------------------------------------------------ describe
-// One wavefront per keypoint: lane t evaluates tests t, t+64, t+128, t+192;
-// four ballots give the 32 descriptor bytes.  Also writes the final keypoint.
-__global__ __launch_bounds__(256) void describe_kernel(Geom g, const uint8_t* __restrict__ blur,
+// (float)cos / (float)sin of a float angle in [0, 2*pi], evaluated in double so that the
+// rounded float equals the one a double libm gives: Cody-Waite reduction by pi/2 and the
+// classic degree-13/14 minimax kernels on [-pi/4, pi/4].
+__device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    double kd = rint(x * two_over_pi);
+    int k = (int)kd;
+    double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    double z = r * r;
+    double ps = 8.33333333332248946124e-03 +
+                z * (-1.98412698298579493134e-04 +
+                     z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    double pc = z * (4.16666666666666019037e-02 +
+                     z * (-1.38888888888741095749e-03 +
+                          z * (2.48015872894767294178e-05 +
+                               z * (-2.75573143513906633035e-07 +
+                                    z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double c = 1.0 - (0.5 * z - z * pc);
+    switch (k & 3) {
+        case 0: *sn = s; *cs = c; break;
+        case 1: *sn = c; *cs = -s; break;
+        case 2: *sn = -s; *cs = -c; break;
+        default: *sn = -c; *cs = s; break;
+    }
+}
+
+// One wavefront per keypoint (grid-stride over an image's keypoints): the wave first
+// computes the intensity-centroid angle, lane 0 writes the final keypoint, then lane t
+// evaluates tests t, t+64, t+128, t+192 and four ballots give the 32 descriptor bytes.
+__global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
+                                                       const uint8_t* __restrict__ pyr,
+                                                       const uint8_t* __restrict__ blur,
                                                        const uint16_t* __restrict__ kp_x,
                                                        const uint16_t* __restrict__ kp_y,
                                                        const float* __restrict__ kp_resp,
-                                                       const float* __restrict__ kp_angle,
                                                        const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int cap, int32_t* __restrict__ counts,
                                                        uint32_t* __restrict__ flags) {
-    int l = blockIdx.y, img = blockIdx.z;
-    int lane = threadIdx.x & 63;
-    int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
     const uint32_t* cnt = kp_cnt + img * kLevels;
-    int base_idx = 0, total = 0;
+    int start[kLevels + 1];
+    start[0] = 0;
 #pragma unroll
-    for (int k = 0; k < kLevels; ++k) {
-        int c = cnt[k];
-        if (k < l) base_idx += c;
-        total += c;
-    }
-    if (l == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < kLevels; ++k) start[k + 1] = start[k] + (int)cnt[k];
+    const int total = start[kLevels];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         counts[img] = min(total, cap);
         if (total > cap) atomicOr(flags, 4u);
     }
-    if (slot >= (int)cnt[l]) return;
-    int oi = base_idx + slot;
-    if (oi >= cap) return;
-    const LevelGeom& L = g.L[l];
-    size_t ib = (size_t)img * g.kp_stride + L.kp_off + slot;
-    int x = kp_x[ib], y = kp_y[ib];
-    float angle = kp_angle[ib];
-    float fx = (float)x * L.scale, fy = (float)y * L.scale;
-    if (lane == 0) {
-        vo_keypoint k;
-        k.x = fx;
-        k.y = fy;
-        k.size = 31 * L.scale;
-        k.angle = angle;
-        k.response = kp_resp[ib];
-        k.octave = l;
-        k.class_id = -1;
-        kps[(size_t)img * cap + oi] = k;
-    }
-    if (!desc) return;
-    float inv = 1.f / L.scale;
-    int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-    float ar = angle * (float)(M_PI / 180.f);
-    float a = (float)cos((double)ar), b = (float)sin((double)ar);
-    const uint8_t* center = blur + (size_t)img * g.blk_stride + L.off + (size_t)cy * L.pitch + cx;
-    const int pitch = L.pitch;
-    unsigned long long bits[4];
+    const int n = min(total, cap);
+    for (int oi = blockIdx.x * 4 + (threadIdx.x >> 6); oi < n; oi += gridDim.x * 4) {
+        int l = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int8_t* p = &d_pattern[(k * 64 + lane) * 4];
-        float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
-        float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
-        float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-        int t0 = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
-        int t1 = center[__float2int_rn(ry1) * pitch + __float2int_rn(rx1)];
-        bits[k] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        *reinterpret_cast<unsigned long long*>(desc + ((size_t)img * cap + oi) * 32 + lane * 8) = v;
+        for (int k = 1; k < kLevels; ++k) l += (oi >= start[k]);
+        int lstart = 0;
+#pragma unroll
+        for (int k = 1; k < kLevels; ++k) lstart = (oi >= start[k]) ? start[k] : lstart;
+        const int slot = oi - lstart;
+        const LevelGeom& L = g.L[l];
+        size_t ib = (size_t)img * g.kp_stride + L.kp_off + slot;
+        int x = kp_x[ib], y = kp_y[ib];
+        // orientation: the 31-px disc is split over the wave (lanes 0-31 take rows v >= 0,
+        // lanes 32-63 rows v < 0, one column each); integer moments, order-independent
+        float angle;
+        {
+            int lpitch;
+            const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
+            const uint8_t* ctr = lbase + (size_t)y * lpitch + x;
+            int u = (lane & 31) - kHalfPatch, neg = lane >> 5;
+            int au = u < 0 ? -u : u;
+            int m10 = 0, m01 = 0;
+            // every address within 16 px of a keypoint is inside the level (keypoints keep a
+            // 31-px margin), so all 16 loads are issued unconditionally and masked afterwards
+            int vals[kHalfPatch + 1];
+#pragma unroll
+            for (int r = 0; r <= kHalfPatch; ++r) vals[r] = ctr[(neg ? -r : r) * lpitch + u];
+#pragma unroll
+            for (int r = 0; r <= kHalfPatch; ++r) {
+                int val = (au <= tabs.umax[r] && !(neg && r == 0)) ? vals[r] : 0;
+                m10 += u * val;
+                m01 += (neg ? -r : r) * val;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                m10 += __shfl_xor(m10, o);
+                m01 += __shfl_xor(m01, o);
+            }
+            angle = fast_atan2_deg((float)m01, (float)m10);
+        }
+        float fx = (float)x * L.scale, fy = (float)y * L.scale;
+        if (lane == 0) {
+            vo_keypoint k;
+            k.x = fx;
+            k.y = fy;
+            k.size = 31 * L.scale;
+            k.angle = angle;
+            k.response = kp_resp[ib];
+            k.octave = l;
+            k.class_id = -1;
+            kps[(size_t)img * cap + oi] = k;
+        }
+        if (!desc) continue;
+        float inv = 1.f / L.scale;
+        int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
+        float ar = angle * (float)(M_PI / 180.f);
+        double sd, cd;
+        sincos_f64((double)ar, &sd, &cd);
+        float a = (float)cd, b = (float)sd;
+        const uint8_t* center = blur + (size_t)img * g.blk_stride + L.off + (size_t)cy * L.pitch + cx;
+        const int pitch = L.pitch;
+        unsigned long long bits[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int8_t* p = &d_pattern[(k * 64 + lane) * 4];
+            float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+            float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
+            float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
+            int t0 = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
+            int t1 = center[__float2int_rn(ry1) * pitch + __float2int_rn(rx1)];
+            bits[k] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            *reinterpret_cast<unsigned long long*>(desc + ((size_t)img * cap + oi) * 32 + lane * 8) = v;
+        }
     }
 }
 
@@ -693,7 +818,9 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
     if ((rc = ensure(c, c->kp_x, N * g.kp_stride * 2))) return rc;
     if ((rc = ensure(c, c->kp_y, N * g.kp_stride * 2))) return rc;
     if ((rc = ensure(c, c->kp_resp, N * g.kp_stride * 4))) return rc;
-    if ((rc = ensure(c, c->kp_angle, N * g.kp_stride * 4))) return rc;
+    if ((rc = ensure(c, c->sel_keys, N * kLevels * (size_t)g.sel_cap * 4))) return rc;
+    if ((rc = ensure(c, c->sel_resp, N * kLevels * (size_t)g.sel_cap * 4))) return rc;
+    if ((rc = ensure(c, c->sel_cnt, N * kLevels * 4))) return rc;
     if ((rc = ensure(c, c->kp_cnt, N * kLevels * 4))) return rc;
     if ((rc = ensure(c, c->flags, 256))) return rc;
     return VO_OK;
@@ -722,11 +849,20 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         t_end(c, VO_T_FAST);
     }
     t_begin(c, VO_T_SELECT);
+    int sel_need = 0;   // upper bound of a level's list after the first cut, for the Harris grid
+    for (int l = 0; l < kLevels; ++l) sel_need = std::max(sel_need, std::min(g.sel_cap, g.L[l].cand_cap));
 #define VO_SELECT(CAPV)                                                                                              \
-    hipLaunchKernelGGL(select_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g, tabs, d_imgs, pyr,                \
-                       (const uint32_t*)c->cand.p, (const uint32_t*)c->cand_cnt.p, (uint16_t*)c->kp_x.p,            \
-                       (uint16_t*)c->kp_y.p, (float*)c->kp_resp.p, (float*)c->kp_angle.p, (uint32_t*)c->kp_cnt.p,   \
-                       (uint32_t*)c->flags.p)
+    do {                                                                                                             \
+        hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
+                           (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
+                           (uint32_t*)c->flags.p);                                                                   \
+        hipLaunchKernelGGL(harris_kernel, dim3((sel_need + 255) / 256, kLevels, N), dim3(256), 0, s, g, CAPV, d_imgs, \
+                           pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
+        hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g,                              \
+                           (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
+                           (const float*)c->sel_resp.p, (uint16_t*)c->kp_x.p, (uint16_t*)c->kp_y.p,                  \
+                           (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p);                     \
+    } while (0)
     if (g.sel_cap == 2048) VO_SELECT(2048);
     else if (g.sel_cap == 4096) VO_SELECT(4096);
     else VO_SELECT(8192);
@@ -739,11 +875,9 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         t_end(c, VO_T_BLUR);
     }
     t_begin(c, VO_T_DESCRIBE);
-    int max_kp = 0;
-    for (int l = 0; l < kLevels; ++l) max_kp = std::max(max_kp, g.L[l].kp_cap);
-    hipLaunchKernelGGL(describe_kernel, dim3((max_kp + 3) / 4, kLevels, N), dim3(256), 0, s, g,
+    hipLaunchKernelGGL(describe_kernel, dim3(std::max((g.max_features + 3) / 4, 1), N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
                        (const uint8_t*)c->blur.p, (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p,
-                       (const float*)c->kp_resp.p, (const float*)c->kp_angle.p, (const uint32_t*)c->kp_cnt.p, d_kps,
+                       (const float*)c->kp_resp.p, (const uint32_t*)c->kp_cnt.p, d_kps,
                        d_desc, cap, d_counts, (uint32_t*)c->flags.p);
     t_end(c, VO_T_DESCRIBE);
     VO_HIP(c, hipGetLastError());
