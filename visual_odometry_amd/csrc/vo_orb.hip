@@ -13,7 +13,7 @@ namespace vo {
 static const int8_t h_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
-__device__ int8_t d_pattern[256 * 4];
+__device__ __attribute__((aligned(16))) int8_t d_pattern[256 * 4];
 static bool g_pattern_loaded[64] = {false};
 
 struct SmallTabs {
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
 // ------------------------------------------------------------------ FAST
 constexpr int FT_W = 64, FT_H = 32;
 constexpr int FP_W = 80, FP_H = FT_H + 8;   // pixel tile (dword-aligned origin, 4-px halo)
-constexpr int FS_W = 68, FS_H = FT_H + 2;   // score tile (1-px halo)
+constexpr int FS_W = 68, FS_H = FT_H + 2;   // score tile (1-px halo), logical width FT_W + 2
+constexpr int FQ_N = FS_H * (FT_W + 2);     // positions whose score is needed
 
 __device__ __forceinline__ bool has_arc9(unsigned m) {
     m |= m << 16;
@@ -86,23 +87,19 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
     return (a & 0xFFFFu) != 0;
 }
 
-// FAST-9/16 corner score at LDS pixel p: 0 if no 9-arc is beyond the
-// threshold, else max over arcs of the arc's minimum contrast, minus 1.
-__device__ __forceinline__ int fast_score_lds(const uint8_t* p) {
+// centre minus the 16 ring pixels (Bresenham circle of radius 3, OpenCV's order)
+__device__ __forceinline__ void ring_diffs(const uint8_t* p, int* d) {
     constexpr int P = FP_W;
     const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
                          -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
     int v = p[0];
-    int d[16];
-    unsigned bright = 0, dark = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        d[k] = v - (int)p[off[k]];
-        bright |= (unsigned)(d[k] > kFastThr) << k;
-        dark |= (unsigned)(d[k] < -kFastThr) << k;
-    }
-    bool hb = has_arc9(bright), hd = has_arc9(dark);
-    if (!hb && !hd) return 0;
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)p[off[k]];
+}
+
+// FAST-9/16 score of a pixel known to be a corner: max over 9-arcs of the arc's minimum
+// contrast (bright or dark), minus 1 - what cornerScore<16> returns.
+__device__ __forceinline__ int corner_score(const int* d) {
     int mn[16], mx[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -126,15 +123,33 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* p) {
     return max(A, -B) - 1;
 }
 
+// Appends `val` for the lanes with pass == true to an LDS queue: one atomic per wavefront.
+__device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, uint32_t* cnt, int lane) {
+    unsigned long long m = __ballot(pass);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (pass) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = val;
+}
+
+// One launch over every level's 64x32 tiles of the 31-px interior.  Three filters of
+// growing cost, each feeding the next through a wavefront-compacted LDS queue so that the
+// expensive stages run on dense wavefronts:
+//   1. four cardinal ring pixels: a 9-arc always contains two adjacent cardinals;
+//   2. the full 16-pixel ring masks and the 9-contiguous test;
+//   3. the corner score (min/max ladder), written to an LDS score tile;
+// then 3x3 non-max suppression, the border filter and one global atomic per tile.
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                                    uint32_t* __restrict__ cand_cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t px[FP_H * FP_W];
-    __shared__ uint8_t sc[FS_H * FS_W];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
+    __shared__ uint16_t q1[FQ_N], q2[FQ_N];
     __shared__ uint32_t list[FT_W * FT_H / 4];
-    __shared__ uint32_t nlist, gbase;
+    __shared__ uint32_t n1, n2, nlist, gbase;
 
-    int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     int l = 0;
 #pragma unroll
     for (int k = 0; k < kLevels; ++k) {
@@ -147,7 +162,12 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
     int ax0 = (x0 - 4) & ~3;   // LDS column 0 <-> image column ax0
-    if (tid == 0) nlist = 0;
+    if (tid == 0) {
+        n1 = 0;
+        n2 = 0;
+        nlist = 0;
+    }
+    for (int i = tid; i < FS_H * FS_W / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
 
     bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
     if (aligned) {
@@ -169,27 +189,74 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
 
-    // scores on the (FT_W+2) x (FT_H+2) halo region
-    for (int i = tid; i < FS_H * (FT_W + 2); i += 256) {
-        int sy = i / (FT_W + 2), sx = i - sy * (FT_W + 2);
-        int X = x0 - 1 + sx, Y = y0 - 1 + sy;
-        int s = 0;
-        if (X <= L.w - kEdge && Y <= L.h - kEdge) s = fast_score_lds(&px[(sy + 3) * FP_W + (X - ax0)]);
-        sc[sy * FS_W + sx] = (uint8_t)s;
+    // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed
+    const int cx0 = x0 - 1 - ax0;   // LDS column of score column 0
+    for (int i0 = 0; i0 < FQ_N; i0 += 256) {
+        int i = i0 + tid;
+        bool pass = false;
+        if (i < FQ_N) {
+            int sy = i / (FT_W + 2), sx = i - sy * (FT_W + 2);
+            int X = x0 - 1 + sx, Y = y0 - 1 + sy;
+            if (X <= L.w - kEdge && Y <= L.h - kEdge) {
+                const uint8_t* p = &px[(sy + 3) * FP_W + cx0 + sx];
+                int v = p[0];
+                int d0 = v - (int)p[3 * FP_W], d4 = v - (int)p[3], d8 = v - (int)p[-3 * FP_W], d12 = v - (int)p[-3];
+                bool b0 = d0 > kFastThr, b4 = d4 > kFastThr, b8 = d8 > kFastThr, b12 = d12 > kFastThr;
+                bool k0 = d0 < -kFastThr, k4 = d4 < -kFastThr, k8 = d8 < -kFastThr, k12 = d12 < -kFastThr;
+                pass = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
+            }
+        }
+        wave_push(pass, (uint16_t)i, q1, &n1, lane);
     }
     __syncthreads();
 
-    // 3x3 non-max suppression + border filter on the interior
-    for (int i = tid; i < FT_W * FT_H; i += 256) {
-        int iy = i / FT_W, ix = i - iy * FT_W;
-        int X = x0 + ix, Y = y0 + iy;
-        const uint8_t* s = &sc[(iy + 1) * FS_W + ix + 1];
-        int v = s[0];
-        bool keep = v > 0 && X < L.w - kEdge && Y < L.h - kEdge;
-        if (keep) {
-            keep = v > s[-1] && v > s[1] && v > s[-FS_W - 1] && v > s[-FS_W] && v > s[-FS_W + 1] && v > s[FS_W - 1] &&
-                   v > s[FS_W] && v > s[FS_W + 1];
+    // stage 2: full ring test
+    const uint32_t c1 = n1;
+    for (uint32_t i0 = 0; i0 < c1; i0 += 256) {
+        uint32_t i = i0 + tid;
+        bool pass = false;
+        uint16_t pos = 0;
+        if (i < c1) {
+            pos = q1[i];
+            int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
+            int d[16];
+            ring_diffs(&px[(sy + 3) * FP_W + cx0 + sx], d);
+            // ring masks through the sign bit: mask = (mask << 1) | sign(thr - d) is one
+            // v_alignbit per ring pixel (the reversed bit order keeps arcs contiguous)
+            unsigned bright = 0, dark = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(kFastThr - d[k]), 31);
+                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(kFastThr + d[k]), 31);
+            }
+            pass = has_arc9(bright & 0xFFFFu) || has_arc9(dark & 0xFFFFu);
         }
+        wave_push(pass, pos, q2, &n2, lane);
+    }
+    __syncthreads();
+
+    // stage 3: corner scores
+    const uint32_t c2 = n2;
+    for (uint32_t i = tid; i < c2; i += 256) {
+        uint16_t pos = q2[i];
+        int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
+        int d[16];
+        ring_diffs(&px[(sy + 3) * FP_W + cx0 + sx], d);
+        sc[sy * FS_W + sx] = (uint8_t)corner_score(d);
+    }
+    __syncthreads();
+
+    // 3x3 non-max suppression + border filter on the interior (only corners need the look-up)
+    for (uint32_t i = tid; i < c2; i += 256) {
+        uint16_t pos = q2[i];
+        int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
+        int ix = sx - 1, iy = sy - 1;
+        int X = x0 + ix, Y = y0 + iy;
+        if (ix < 0 || iy < 0 || ix >= FT_W || iy >= FT_H || X >= L.w - kEdge || Y >= L.h - kEdge) continue;
+        const uint8_t* s = &sc[sy * FS_W + sx];
+        int v = s[0];
+        bool keep = v > s[-1] && v > s[1] && v > s[-FS_W - 1] && v > s[-FS_W] && v > s[-FS_W + 1] && v > s[FS_W - 1] &&
+                    v > s[FS_W] && v > s[FS_W + 1];
         if (keep) {
             uint32_t slot = atomicAdd(&nlist, 1u);
             list[slot] = ((uint32_t)v << 24) | ((uint32_t)Y << 12) | (uint32_t)X;
@@ -604,6 +671,10 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
         if (total > cap) atomicOr(flags, 4u);
     }
     const int n = min(total, cap);
+    // this lane's four tests are the same for every keypoint: fetch them once
+    int pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 64 + lane];
     for (int oi = blockIdx.x * 4 + (threadIdx.x >> 6); oi < n; oi += gridDim.x * 4) {
         int l = 0;
 #pragma unroll
@@ -667,8 +738,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
         unsigned long long bits[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int8_t* p = &d_pattern[(k * 64 + lane) * 4];
-            float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+            float x0 = (float)(int8_t)(pat[k] & 0xFF), y0 = (float)(int8_t)((pat[k] >> 8) & 0xFF);
+            float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
             float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
             float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
             int t0 = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
