@@ -31,6 +31,14 @@ __device__ __forceinline__ const uint8_t* level_base(const Geom& g, const uint8_
     return pyr + (size_t)img * g.blk_stride + g.L[l].off;
 }
 
+// Four bytes at an arbitrary byte address (one global_load_dword; gfx950 global loads need
+// no alignment).
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // ------------------------------------------------------------------ resize
 // Level l from level l-1, INTER_LINEAR_EXACT semantics: 8.8 coefficients,
 // out = (m0*(c0*a + c1*b) + m1*(c0*c + c1*d) + 2^15) >> 16.
@@ -52,22 +60,41 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
     int sy1 = min(sy + 1, S.h - 1);
     const uint8_t* r0 = src + (size_t)sy * spitch;
     const uint8_t* r1 = src + (size_t)sy1 * spitch;
-    uint32_t outw = 0;
+    uint32_t tx[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int x = x4 + k;
-        uint32_t v = 0;
-        if (x < D.w) {
-            uint32_t tx = tab[D.xtab + x];
-            int sx = tx >> 16;
-            uint32_t c1 = tx & 0xFFFF, c0 = 256 - c1;
-            int sx1 = min(sx + 1, S.w - 1);
-            uint32_t h0 = c0 * r0[sx] + c1 * r0[sx1];
-            uint32_t h1 = c0 * r1[sx] + c1 * r1[sx1];
-            v = (m0 * h0 + m1 * h1 + 32768u) >> 16;
-            v = min(v, 255u);
+    for (int k = 0; k < 4; ++k) tx[k] = tab[D.xtab + min(x4 + k, D.w - 1)];
+    // The four outputs read source columns sx0 .. sx0+6 at most (scale 1.2): fetch eight
+    // bytes per row with two unaligned dword loads when that stays inside the row.
+    int sx0 = tx[0] >> 16;
+    uint32_t outw = 0;
+    if (sx0 + 8 <= S.w) {
+        unsigned long long a = load_u32_unaligned(r0 + sx0) | ((unsigned long long)load_u32_unaligned(r0 + sx0 + 4) << 32);
+        unsigned long long b = load_u32_unaligned(r1 + sx0) | ((unsigned long long)load_u32_unaligned(r1 + sx0 + 4) << 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int o = (int)(tx[k] >> 16) - sx0;   // 0..5
+            uint32_t c1 = tx[k] & 0xFFFF, c0 = 256 - c1;
+            uint32_t a0 = (uint32_t)(a >> (8 * o)) & 0xFFu, a1 = (uint32_t)(a >> (8 * o + 8)) & 0xFFu;
+            uint32_t b0 = (uint32_t)(b >> (8 * o)) & 0xFFu, b1 = (uint32_t)(b >> (8 * o + 8)) & 0xFFu;
+            uint32_t h0 = c0 * a0 + c1 * a1;
+            uint32_t h1 = c0 * b0 + c1 * b1;
+            uint32_t v = min((m0 * h0 + m1 * h1 + 32768u) >> 16, 255u);
+            outw |= v << (8 * k);
         }
-        outw |= v << (8 * k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = 0;
+            if (x4 + k < D.w) {
+                int sx = tx[k] >> 16;
+                uint32_t c1 = tx[k] & 0xFFFF, c0 = 256 - c1;
+                int sx1 = min(sx + 1, S.w - 1);
+                uint32_t h0 = c0 * r0[sx] + c1 * r0[sx1];
+                uint32_t h1 = c0 * r1[sx] + c1 * r1[sx1];
+                v = min((m0 * h0 + m1 * h1 + 32768u) >> 16, 255u);
+            }
+            outw |= v << (8 * k);
+        }
     }
     *reinterpret_cast<uint32_t*>(dst + x4) = outw;  // pitch is a multiple of 64: the store stays inside the row
 }
@@ -281,25 +308,34 @@ __device__ __forceinline__ uint32_t f2sortable(float f) {
     return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
+// HarrisResponses: 7x7 block of Sobel-like gradients around (x0, y0), int32 sums, float32
+// response in OpenCV's operation order.  The 9x9 support is fetched as 9 rows of three
+// unaligned dwords and walked with a three-row register window.
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x0, int y0) {
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
-    int a = 0, b = 0, c = 0;
-    for (int i = -3; i <= 3; ++i) {
-        const uint8_t* rm = img + (size_t)(y0 + i - 1) * pitch + x0;
-        const uint8_t* r0 = rm + pitch;
-        const uint8_t* rp = r0 + pitch;
+    uint32_t w[9][3];
 #pragma unroll
-        for (int j = -3; j <= 3; ++j) {
-            int Ix = ((int)r0[j + 1] - (int)r0[j - 1]) * 2 + ((int)rm[j + 1] - (int)rm[j - 1]) +
-                     ((int)rp[j + 1] - (int)rp[j - 1]);
-            int Iy = ((int)rp[j] - (int)rm[j]) * 2 + ((int)rp[j - 1] - (int)rm[j - 1]) +
-                     ((int)rp[j + 1] - (int)rm[j + 1]);
+    for (int r = 0; r < 9; ++r) {
+        const uint8_t* p = img + (size_t)(y0 - 4 + r) * pitch + (x0 - 4);
+        w[r][0] = load_u32_unaligned(p);
+        w[r][1] = load_u32_unaligned(p + 4);
+        w[r][2] = load_u32_unaligned(p + 8);
+    }
+    auto px = [&](int r, int c) -> int { return (int)((w[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
+    int a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int i = 1; i <= 7; ++i)
+#pragma unroll
+        for (int j = 1; j <= 7; ++j) {
+            int Ix = (px(i, j + 1) - px(i, j - 1)) * 2 + (px(i - 1, j + 1) - px(i - 1, j - 1)) +
+                     (px(i + 1, j + 1) - px(i + 1, j - 1));
+            int Iy = (px(i + 1, j) - px(i - 1, j)) * 2 + (px(i + 1, j - 1) - px(i - 1, j - 1)) +
+                     (px(i + 1, j + 1) - px(i - 1, j + 1));
             a += Ix * Ix;
             b += Iy * Iy;
             c += Ix * Iy;
         }
-    }
     float fa = (float)a, fb = (float)b, fc = (float)c;
     float t1 = fa * fb;
     float t2 = fc * fc;
@@ -646,9 +682,11 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
     }
 }
 
-// One wavefront per keypoint (grid-stride over an image's keypoints): the wave first
-// computes the intensity-centroid angle, lane 0 writes the final keypoint, then lane t
-// evaluates tests t, t+64, t+128, t+192 and four ballots give the 32 descriptor bytes.
+// Half a wavefront (32 lanes) per keypoint, two keypoints per wave, grid-stride over an
+// image's keypoints: the half-wave first computes the intensity-centroid angle (lane = column
+// of the 31-px disc), its first lane writes the final keypoint, then lane t evaluates tests
+// t, t+32, ..., t+224 and eight ballots give the 32 descriptor bytes (low word: first
+// keypoint, high word: second).
 __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
                                                        const uint8_t* __restrict__ pyr,
                                                        const uint8_t* __restrict__ blur,
@@ -659,7 +697,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
                                                        uint8_t* __restrict__ desc, int cap, int32_t* __restrict__ counts,
                                                        uint32_t* __restrict__ flags) {
     const int img = blockIdx.y;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const uint32_t* cnt = kp_cnt + img * kLevels;
     int start[kLevels + 1];
     start[0] = 0;
@@ -671,51 +709,51 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
         if (total > cap) atomicOr(flags, 4u);
     }
     const int n = min(total, cap);
-    // this lane's four tests are the same for every keypoint: fetch them once
-    int pat[4];
+    // this lane's eight tests are the same for every keypoint: fetch them once
+    int pat[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 64 + lane];
-    for (int oi = blockIdx.x * 4 + (threadIdx.x >> 6); oi < n; oi += gridDim.x * 4) {
-        int l = 0;
+    for (int k = 0; k < 8; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
+    for (int o2 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += gridDim.x * 8) {
+        const bool live = o2 + half < n;          // an odd count leaves the last second half idle
+        const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
+        int l = 0, lstart = 0;
 #pragma unroll
-        for (int k = 1; k < kLevels; ++k) l += (oi >= start[k]);
-        int lstart = 0;
-#pragma unroll
-        for (int k = 1; k < kLevels; ++k) lstart = (oi >= start[k]) ? start[k] : lstart;
+        for (int k = 1; k < kLevels; ++k) {
+            l += (oi >= start[k]);
+            lstart = (oi >= start[k]) ? start[k] : lstart;
+        }
         const int slot = oi - lstart;
         const LevelGeom& L = g.L[l];
         size_t ib = (size_t)img * g.kp_stride + L.kp_off + slot;
         int x = kp_x[ib], y = kp_y[ib];
-        // orientation: the 31-px disc is split over the wave (lanes 0-31 take rows v >= 0,
-        // lanes 32-63 rows v < 0, one column each); integer moments, order-independent
         float angle;
         {
             int lpitch;
             const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
-            const uint8_t* ctr = lbase + (size_t)y * lpitch + x;
-            int u = (lane & 31) - kHalfPatch, neg = lane >> 5;
-            int au = u < 0 ? -u : u;
-            int m10 = 0, m01 = 0;
+            const int u = hl - kHalfPatch, au = u < 0 ? -u : u;      // lane 31: u = 16, masked out
+            const uint8_t* col = lbase + (size_t)y * lpitch + x + u;
             // every address within 16 px of a keypoint is inside the level (keypoints keep a
-            // 31-px margin), so all 16 loads are issued unconditionally and masked afterwards
-            int vals[kHalfPatch + 1];
+            // 31-px margin): all 31 loads are issued unconditionally and masked afterwards
+            int vals[2 * kHalfPatch + 1];
 #pragma unroll
-            for (int r = 0; r <= kHalfPatch; ++r) vals[r] = ctr[(neg ? -r : r) * lpitch + u];
+            for (int r = -kHalfPatch; r <= kHalfPatch; ++r) vals[r + kHalfPatch] = col[r * lpitch];
+            int m10 = 0, m01 = 0;
 #pragma unroll
-            for (int r = 0; r <= kHalfPatch; ++r) {
-                int val = (au <= tabs.umax[r] && !(neg && r == 0)) ? vals[r] : 0;
-                m10 += u * val;
-                m01 += (neg ? -r : r) * val;
+            for (int r = -kHalfPatch; r <= kHalfPatch; ++r) {
+                int val = au <= tabs.umax[r < 0 ? -r : r] ? vals[r + kHalfPatch] : 0;
+                m10 += val;
+                m01 += r * val;
             }
+            m10 *= u;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = 16; o > 0; o >>= 1) {
                 m10 += __shfl_xor(m10, o);
                 m01 += __shfl_xor(m01, o);
             }
             angle = fast_atan2_deg((float)m01, (float)m10);
         }
         float fx = (float)x * L.scale, fy = (float)y * L.scale;
-        if (lane == 0) {
+        if (hl == 0 && live) {
             vo_keypoint k;
             k.x = fx;
             k.y = fy;
@@ -735,21 +773,24 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
         float a = (float)cd, b = (float)sd;
         const uint8_t* center = blur + (size_t)img * g.blk_stride + L.off + (size_t)cy * L.pitch + cx;
         const int pitch = L.pitch;
-        unsigned long long bits[4];
+        int t0[8], t1[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             float x0 = (float)(int8_t)(pat[k] & 0xFF), y0 = (float)(int8_t)((pat[k] >> 8) & 0xFF);
             float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
             float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
             float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-            int t0 = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
-            int t1 = center[__float2int_rn(ry1) * pitch + __float2int_rn(rx1)];
-            bits[k] = __ballot(t0 < t1);
+            t0[k] = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
+            t1[k] = center[__float2int_rn(ry1) * pitch + __float2int_rn(rx1)];
         }
-        if (lane < 4) {
-            unsigned long long v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-            *reinterpret_cast<unsigned long long*>(desc + ((size_t)img * cap + oi) * 32 + lane * 8) = v;
+        uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long m = __ballot(t0[k] < t1[k]);
+            uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+            if (hl == k) mine = w;
         }
+        if (hl < 8 && live) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi) * 32 + hl * 4) = mine;
     }
 }
 
@@ -946,7 +987,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         t_end(c, VO_T_BLUR);
     }
     t_begin(c, VO_T_DESCRIBE);
-    hipLaunchKernelGGL(describe_kernel, dim3(std::max((g.max_features + 3) / 4, 1), N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
+    hipLaunchKernelGGL(describe_kernel, dim3(std::max((g.max_features + 7) / 8, 1), N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
                        (const uint8_t*)c->blur.p, (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p,
                        (const float*)c->kp_resp.p, (const uint32_t*)c->kp_cnt.p, d_kps,
                        d_desc, cap, d_counts, (uint32_t*)c->flags.p);
