@@ -15,8 +15,19 @@ namespace vo {
 
 constexpr int MT_ROWS = 256;   // train rows per LDS tile (8 KiB)
 
-// median of (a, b, c) given a <= b: the compiler folds this to one v_med3_u32
-__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) { return min(b, max(a, c)); }
+// One instruction each: the compiler otherwise turns the popcount chain into
+// v_bcnt(x, 0) + v_add3 trees and the median into max + min, 23 VALU instructions per
+// (query, train row) instead of 19.  Integer VALU issue is what bounds this kernel.
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {   // popcount(x) + acc
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 
 // Two smallest of {a0<=a1} U {b0<=b1} as 64-bit keys (distance << 32 | row).
 __device__ __forceinline__ void merge2(unsigned long long& a0, unsigned long long& a1, unsigned long long b0,
@@ -74,26 +85,34 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
             __syncthreads();
             const int r0 = wave * 64;
             const int rn = min(max(cn - t0 - r0, 0), 64);
-#pragma unroll 4
-            for (int r = 0; r < rn; ++r) {
-                const uint4* tp = reinterpret_cast<const uint4*>(&tile[(r0 + r) * 8]);
-                uint4 ta = tp[0], tc = tp[1];
-                const uint32_t j = (uint32_t)(t0 + r0 + r);
+            auto row_step = [&](const uint4& ta, const uint4& tc, uint32_t j) {
 #pragma unroll
                 for (int k = 0; k < QPL; ++k) {
-                    uint32_t d = __popc(qr[k][0] ^ ta.x);
-                    d += __popc(qr[k][1] ^ ta.y);
-                    d += __popc(qr[k][2] ^ ta.z);
-                    d += __popc(qr[k][3] ^ ta.w);
-                    d += __popc(qr[k][4] ^ tc.x);
-                    d += __popc(qr[k][5] ^ tc.y);
-                    d += __popc(qr[k][6] ^ tc.z);
-                    d += __popc(qr[k][7] ^ tc.w);
+                    uint32_t d = bcnt_acc(qr[k][0] ^ ta.x, 0u);
+                    d = bcnt_acc(qr[k][1] ^ ta.y, d);
+                    d = bcnt_acc(qr[k][2] ^ ta.z, d);
+                    d = bcnt_acc(qr[k][3] ^ ta.w, d);
+                    d = bcnt_acc(qr[k][4] ^ tc.x, d);
+                    d = bcnt_acc(qr[k][5] ^ tc.y, d);
+                    d = bcnt_acc(qr[k][6] ^ tc.z, d);
+                    d = bcnt_acc(qr[k][7] ^ tc.w, d);
                     uint32_t key = (d << 16) | j;
                     k1[k] = med3u(k0[k], k1[k], key);
                     k0[k] = min(k0[k], key);
                 }
+            };
+            const uint4* tp = reinterpret_cast<const uint4*>(&tile[r0 * 8]);
+            const uint32_t jb = (uint32_t)(t0 + r0);
+            int r = 0;
+            for (; r + 4 <= rn; r += 4) {   // four rows' broadcast reads in flight ahead of their use
+                uint4 a0 = tp[2 * r], c0 = tp[2 * r + 1], a1 = tp[2 * r + 2], c1 = tp[2 * r + 3];
+                uint4 a2 = tp[2 * r + 4], c2 = tp[2 * r + 5], a3 = tp[2 * r + 6], c3 = tp[2 * r + 7];
+                row_step(a0, c0, jb + r);
+                row_step(a1, c1, jb + r + 1);
+                row_step(a2, c2, jb + r + 2);
+                row_step(a3, c3, jb + r + 3);
             }
+            for (; r < rn; ++r) row_step(tp[2 * r], tp[2 * r + 1], jb + r);
         }
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
