@@ -27,7 +27,7 @@ WORKLOADS = {
     # name: (height, width, max_features, fixed_iters, default pairs per step)
     "c2_640x480_2000kp": (480, 640, 2000, 0, 256),
     "c3_kitti_1241x376_4000kp": (376, 1241, 4000, 0, 128),
-    "c5_1080p_10000kp_4096hyp": (1080, 1920, 10000, 4096, 8),
+    "c5_1080p_10000kp_4096hyp": (1080, 1920, 10000, 4096, 32),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--workload", default="c2_640x480_2000kp", choices=list(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled up to --pairs)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="contexts (stream + workspace) the steps rotate over; 2 lets one batch's "
+                         "latency-bound RANSAC overlap the next batch's detection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     args = ap.parse_args()
@@ -100,29 +103,37 @@ def main():
         frames += [a, b]
     tiled = [frames[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)]
     imgs = torch.from_numpy(np.stack(tiled)).cuda()
-    res = torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-
-    ctx = capi.Context(local_rank)
+    n_streams = max(1, args.streams)
+    ctxs = [capi.Context(local_rank) for _ in range(n_streams)]
+    ress = [torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(n_streams)]
+    ctx, res = ctxs[0], ress[0]
+    counter = [0]
 
     def step():
-        ctx.pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
-                               res.data_ptr())
+        k = counter[0] % n_streams
+        counter[0] += 1
+        ctxs[k].pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+                                   ress[k].data_ptr())
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_streams)):
         step()
     fence()
-    ctx.set_timing(True)   # drop the warm-up launches from the per-kernel event statistics
+    for c in ctxs:
+        c.set_timing(True)   # drop the warm-up launches from the per-kernel event statistics
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    # per-kernel-group event times (with more than one stream they include whatever the
+    # other stream's kernels take from the GPU meanwhile)
     kernel_ms = {name: ctx.kernel_time_ms(g)[0] for g, name in enumerate(capi.T_GROUPS)}
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -147,7 +158,8 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": args.workload, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct,
                    "image": f"{W}x{H}", "max_features": nfeat, "ratio": 0.75,
-                   "ransac": "adaptive<=1000" if fixed == 0 else f"fixed {fixed}", "parallelism": f"pairs x{world}"},
+                   "ransac": "adaptive<=1000" if fixed == 0 else f"fixed {fixed}", "parallelism": f"pairs x{world}",
+                   "streams_per_gpu": n_streams},
         "roofline": {"bound": "hbm", "kernel": "fast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": fast_avg_ms, "algorithmic_bytes_per_launch": fast_bytes},

@@ -267,6 +267,52 @@ def test_motion_validity_rules(ctx):
     assert r["inliers"] == 0 or r["valid"]
 
 
+# ------------------------------------------------------------------ the large configurations
+def test_full_hd_10k_keypoints_4096_hypotheses(ctx, oracle):
+    # 1920x1080, 10 000 keypoints, fixed 4096-hypothesis RANSAC (no early exit)
+    a, b = synth.frame_pair(61, height=1080, width=1920)
+    K = synth.default_K(1920, 1080)
+    ga, gda = ctx.orb_detect(a, 10000)
+    oa, oda = oracle.orb_detect(a, 10000)
+    assert len(ga) == len(oa) >= 9000
+    assert ga.tobytes() == oa.tobytes() and np.array_equal(gda, oda)
+    gb, gdb = ctx.orb_detect(b, 10000)
+    gq, gt, gd = ctx.match_ratio(gda, gdb)
+    oq, ot, od = oracle.match(gda, gdb)
+    assert np.array_equal(gq, oq) and np.array_equal(gt, ot) and np.array_equal(gd, od)
+    p1 = np.stack([ga["x"][gq], ga["y"][gq]], 1)
+    p2 = np.stack([gb["x"][gt], gb["y"][gt]], 1)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, K, fixed_iters=4096)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, K, fixed_iters=4096)
+    assert git == oit == 4096 and np.array_equal(gsamp, osamp)
+    assert gg == og and np.array_equal(gm, om)
+    g = ctx.estimate_motion(p1, p2, K, fixed_iters=4096)
+    o = oracle.estimate_motion(p1, p2, K, fixed_iters=4096)
+    assert g["valid"] and g["inliers"] == o["inliers"]
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01 and np.linalg.norm(g["t"] - o["t"]) < 1e-4
+
+
+def test_kitti_shape_pipeline_pair(ctx, oracle):
+    # 1241x376, 4000 keypoints through the fused device-resident path
+    import torch
+    from visual_odometry_amd import capi
+    a, b = synth.frame_pair(62, height=376, width=1241)
+    imgs = torch.from_numpy(np.stack([a, b])).cuda()
+    res = torch.zeros(capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_pairs_dev(imgs.data_ptr(), 1, 376, 1241, 1241, 376 * 1241, 4000, 0.75, KITTI_K, 1.0, 0.999, 0,
+                           res.data_ptr())
+    ctx.sync()
+    r = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)[0]
+    ka, da = oracle.orb_detect(a, 4000)
+    kb, db = oracle.orb_detect(b, 4000)
+    qi, ti, _ = oracle.match(da, db)
+    o = oracle.estimate_motion(np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1),
+                               KITTI_K)
+    assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi))
+    assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"]
+    assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4
+
+
 # ------------------------------------------------------------------ fused pipeline
 def test_pipeline_pairs_matches_oracle(ctx, oracle):
     import torch

@@ -216,24 +216,30 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
 
-    // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed
+    // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed.
+    // Lane = column, wave = row phase, so the loop carries one pointer and one row counter;
+    // the two surplus columns (64, 65) are swept by a second, short pass.
     const int cx0 = x0 - 1 - ax0;   // LDS column of score column 0
-    for (int i0 = 0; i0 < FQ_N; i0 += 256) {
-        int i = i0 + tid;
-        bool pass = false;
-        if (i < FQ_N) {
-            int sy = i / (FT_W + 2), sx = i - sy * (FT_W + 2);
-            int X = x0 - 1 + sx, Y = y0 - 1 + sy;
-            if (X <= L.w - kEdge && Y <= L.h - kEdge) {
-                const uint8_t* p = &px[(sy + 3) * FP_W + cx0 + sx];
-                int v = p[0];
-                int d0 = v - (int)p[3 * FP_W], d4 = v - (int)p[3], d8 = v - (int)p[-3 * FP_W], d12 = v - (int)p[-3];
-                bool b0 = d0 > kFastThr, b4 = d4 > kFastThr, b8 = d8 > kFastThr, b12 = d12 > kFastThr;
-                bool k0 = d0 < -kFastThr, k4 = d4 < -kFastThr, k8 = d8 < -kFastThr, k12 = d12 < -kFastThr;
-                pass = (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
-            }
+    auto pretest = [&](const uint8_t* p) -> bool {
+        int v = p[0];
+        int d0 = v - (int)p[3 * FP_W], d4 = v - (int)p[3], d8 = v - (int)p[-3 * FP_W], d12 = v - (int)p[-3];
+        bool b0 = d0 > kFastThr, b4 = d4 > kFastThr, b8 = d8 > kFastThr, b12 = d12 > kFastThr;
+        bool k0 = d0 < -kFastThr, k4 = d4 < -kFastThr, k8 = d8 < -kFastThr, k12 = d12 < -kFastThr;
+        return (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
+    };
+    const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
+    {
+        const int sx = tid & 63;
+        const bool col_ok = sx <= max_sx;
+        for (int sy = tid >> 6; sy < FS_H; sy += 4) {
+            bool pass = col_ok && sy <= max_sy && pretest(&px[(sy + 3) * FP_W + cx0 + sx]);
+            wave_push(pass, (uint16_t)(sy * (FT_W + 2) + sx), q1, &n1, lane);
         }
-        wave_push(pass, (uint16_t)i, q1, &n1, lane);
+        if (tid < 128) {   // waves 0 and 1, whole waves: columns 64 and 65
+            const int sx2 = FT_W + (tid >> 6), sy = tid & 63;
+            bool pass = sy < FS_H && sx2 <= max_sx && sy <= max_sy && pretest(&px[(min(sy, FS_H - 1) + 3) * FP_W + cx0 + sx2]);
+            wave_push(pass, (uint16_t)(sy * (FT_W + 2) + sx2), q1, &n1, lane);
+        }
     }
     __syncthreads();
 
