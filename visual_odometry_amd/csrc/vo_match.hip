@@ -9,6 +9,8 @@
 // (distance << 16 | train row) so that one v_min and one v_med3 update them
 // and ties resolve to the lower train row exactly as an ascending scan with a
 // strict '<' does.
+#include <cstdlib>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -206,9 +208,16 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
-    // queries per lane: as many as keeps >= ~2048 workgroups' worth of waves in flight
+    // Queries per lane.  One query per lane (59 VGPRs, 8 waves per SIMD) hides the two
+    // barriers of every train tile best and measures fastest on everything up to
+    // 65 536 x 65 536; more queries per lane only pay once the grid is so large that the
+    // train tiles' L2 re-reads (one pass per workgroup) start to matter.
     int qpl = 4;
-    while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 1024) qpl >>= 1;
+    while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
+    if (const char* e = getenv("VO_KNN_QPL")) {   // tuning aid
+        int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) qpl = v;
+    }
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
     hipStream_t s = c->stream;
     t_begin(c, VO_T_KNN2);
