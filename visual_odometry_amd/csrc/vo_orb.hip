@@ -565,22 +565,42 @@ __global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* _
 // 7x7 separable fixed-point blur (taps sum to 257, 8 fractional bits each),
 // BORDER_REFLECT_101.  Column stage rounds sum/65536 half-to-even for columns
 // below (w & ~3) and half-up for the rest, saturating to 255.
-constexpr int BT_W = 64, BT_H = 32;
+constexpr int BT_W = 64, BT_H = 58;
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
     return p;
 }
 
-// Tile = 64 x 32 outputs.  The pixel tile (3-row / 4-column halo, dword-aligned origin)
-// is staged in LDS with dword loads (byte loads with reflection on tiles that touch the
-// border); the row pass produces four outputs per lane with two v_dot4_u32_u8 each on
-// byte-aligned windows (v_alignbyte), the column pass reads four u16 row sums per ds_read.
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v) {   // two i16 -> two saturated u8 (low half)
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 va, vb;
+    __builtin_memcpy(&va, &a, 4);
+    __builtin_memcpy(&vb, &b, 4);
+    return __builtin_amdgcn_udot2(va, vb, c, false);
+}
+
+// Tile = 64 x 58 outputs from 64 source rows (3-row halo), 256 lanes.
+// Row pass: a lane takes two vertically adjacent source rows and four columns; each row
+// sum is two v_dot4_u32_u8 on byte-aligned windows (v_alignbyte) of three source dwords,
+// read straight from global memory on interior tiles and from a reflected LDS copy on
+// tiles that touch the border.  The two rows' u16 sums of a column share one LDS dword.
+// Column pass: a lane takes two adjacent output rows and four columns; both rows read
+// the same four row-pair dwords, so a 7-tap column sum is four v_dot2_u32_u16 with the
+// taps paired (t0,t1)(t2,t3)(t4,t5)(t6,0) for the even row and (0,t0)(t1,t2)(t3,t4)(t5,t6)
+// for the odd one.
 __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     constexpr int PW = BT_W + 8, PH = BT_H + 6;          // LDS column 0 <-> image column x0 - 4
+    static_assert(PH == 64, "row pass covers 32 row pairs in two sweeps of 256 lanes");
     __shared__ __attribute__((aligned(16))) uint8_t px[PH * PW];
-    __shared__ __attribute__((aligned(16))) uint16_t hs[PH * BT_W];
+    __shared__ __attribute__((aligned(16))) uint32_t hs[(PH / 2) * BT_W];
     int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     int l = 0;
 #pragma unroll
@@ -593,69 +613,115 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     int x0 = (tl % L.blur_tx) * BT_W, y0 = (tl / L.blur_tx) * BT_H;
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
-    bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
-    bool interior = aligned && x0 >= 4 && x0 + BT_W + 4 <= L.w && y0 >= 3 && y0 + BT_H + 3 <= L.h;
-    if (interior) {
-        for (int i = tid; i < PH * (PW / 4); i += 256) {
-            int r = i / (PW / 4), c = i - r * (PW / 4);
-            uint32_t v = *reinterpret_cast<const uint32_t*>(base + (size_t)(y0 - 3 + r) * pitch + (x0 - 4) + 4 * c);
-            *reinterpret_cast<uint32_t*>(&px[r * PW + 4 * c]) = v;
-        }
-    } else {
-        for (int i = tid; i < PH * PW; i += 256) {
-            int r = i / PW, c = i - r * PW;
-            int y = reflect101(y0 - 3 + r, L.h), x = reflect101(min(x0 - 4 + c, L.w + 3), L.w);
-            px[i] = base[(size_t)y * pitch + x];
-        }
-    }
-    __syncthreads();
+    const bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
+    const bool interior = aligned && x0 >= 4 && x0 + BT_W + 4 <= L.w && y0 >= 3 && y0 + BT_H + 3 <= L.h;
+
     const uint32_t t0123 = (uint32_t)tabs.taps[0] | ((uint32_t)tabs.taps[1] << 8) | ((uint32_t)tabs.taps[2] << 16) |
                            ((uint32_t)tabs.taps[3] << 24);
     const uint32_t t456 = (uint32_t)tabs.taps[4] | ((uint32_t)tabs.taps[5] << 8) | ((uint32_t)tabs.taps[6] << 16);
-    // row pass: outputs x = 4*gx + j read LDS columns 4*gx + 1 + j .. + 7 + j
-    for (int i = tid; i < PH * (BT_W / 4); i += 256) {
-        int r = i / (BT_W / 4), gx = i - r * (BT_W / 4);
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&px[r * PW + 4 * gx]);
-        uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    // four row sums (outputs 4*gx .. 4*gx+3 read source columns 4*gx-3+j .. 4*gx+3+j,
+    // i.e. bytes 1+j .. 7+j of the three dwords that start at column 4*gx-4)
+    auto row4 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t* o) {
         uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), b0 = __builtin_amdgcn_alignbyte(w2, w1, 1);
         uint32_t a1 = __builtin_amdgcn_alignbyte(w1, w0, 2), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
         uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), b2 = __builtin_amdgcn_alignbyte(w2, w1, 3);
-        uint32_t s0 = __builtin_amdgcn_udot4(a0, t0123, __builtin_amdgcn_udot4(b0, t456, 0u, false), false);
-        uint32_t s1 = __builtin_amdgcn_udot4(a1, t0123, __builtin_amdgcn_udot4(b1, t456, 0u, false), false);
-        uint32_t s2 = __builtin_amdgcn_udot4(a2, t0123, __builtin_amdgcn_udot4(b2, t456, 0u, false), false);
-        uint32_t s3 = __builtin_amdgcn_udot4(w1, t0123, __builtin_amdgcn_udot4(w2, t456, 0u, false), false);
-        uint2 o;
-        o.x = s0 | (s1 << 16);
-        o.y = s2 | (s3 << 16);
-        *reinterpret_cast<uint2*>(&hs[r * BT_W + 4 * gx]) = o;
+        o[0] = __builtin_amdgcn_udot4(a0, t0123, __builtin_amdgcn_udot4(b0, t456, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(a1, t0123, __builtin_amdgcn_udot4(b1, t456, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(a2, t0123, __builtin_amdgcn_udot4(b2, t456, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(w1, t0123, __builtin_amdgcn_udot4(w2, t456, 0u, false), false);
+    };
+    auto store_pair = [&](int rp, int gx, const uint32_t* e, const uint32_t* o) {
+        uint4 v;
+        v.x = e[0] | (o[0] << 16);
+        v.y = e[1] | (o[1] << 16);
+        v.z = e[2] | (o[2] << 16);
+        v.w = e[3] | (o[3] << 16);
+        *reinterpret_cast<uint4*>(&hs[rp * BT_W + 4 * gx]) = v;
+    };
+
+    if (interior) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
+            const uint8_t* p = base + (size_t)(y0 - 3 + 2 * rp) * pitch + (x0 - 4) + 4 * gx;
+            const uint32_t* pe = reinterpret_cast<const uint32_t*>(p);
+            const uint32_t* po = reinterpret_cast<const uint32_t*>(p + pitch);
+            uint32_t e0 = pe[0], e1 = pe[1], e2 = pe[2], o0 = po[0], o1 = po[1], o2 = po[2];
+            uint32_t se[4], so[4];
+            row4(e0, e1, e2, se);
+            row4(o0, o1, o2, so);
+            store_pair(rp, gx, se, so);
+        }
+    } else {
+        // reflected copy of the source window; whole dwords where they lie inside the row
+        for (int i = tid; i < PH * (PW / 4); i += 256) {
+            int r = i / (PW / 4), c = i - r * (PW / 4);
+            int y = reflect101(y0 - 3 + r, L.h);
+            int xs = x0 - 4 + 4 * c;
+            const uint8_t* row = base + (size_t)y * pitch;
+            uint32_t v;
+            if (aligned && xs >= 0 && xs + 3 < L.w) {
+                v = *reinterpret_cast<const uint32_t*>(row + xs);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int x = reflect101(min(xs + b, L.w + 3), L.w);
+                    v |= (uint32_t)row[x] << (8 * b);
+                }
+            }
+            *reinterpret_cast<uint32_t*>(&px[r * PW + 4 * c]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
+            const uint32_t* pe = reinterpret_cast<const uint32_t*>(&px[(2 * rp) * PW + 4 * gx]);
+            const uint32_t* po = reinterpret_cast<const uint32_t*>(&px[(2 * rp + 1) * PW + 4 * gx]);
+            uint32_t se[4], so[4];
+            row4(pe[0], pe[1], pe[2], se);
+            row4(po[0], po[1], po[2], so);
+            store_pair(rp, gx, se, so);
+        }
     }
     __syncthreads();
-    int vec_end = L.w & ~3;
+
+    const uint32_t T0 = (uint32_t)tabs.taps[0], T1 = (uint32_t)tabs.taps[1], T2 = (uint32_t)tabs.taps[2], T3 = (uint32_t)tabs.taps[3],
+                   T4 = (uint32_t)tabs.taps[4], T5 = (uint32_t)tabs.taps[5], T6 = (uint32_t)tabs.taps[6];
+    const uint32_t ke0 = T0 | (T1 << 16), ke1 = T2 | (T3 << 16), ke2 = T4 | (T5 << 16), ke3 = T6;
+    const uint32_t ko0 = T0 << 16, ko1 = T1 | (T2 << 16), ko2 = T3 | (T4 << 16), ko3 = T5 | (T6 << 16);
+    const int vec_end = L.w & ~3;
     uint8_t* out = blur + (size_t)img * g.blk_stride + L.off;   // blur block uses the same offsets
-    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
-        int r = i / (BT_W / 4), gx = i - r * (BT_W / 4);
-        int X = x0 + 4 * gx, Y = y0 + r;
-        if (X >= L.w || Y >= L.h) continue;
-        uint32_t s[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            uint2 h = *reinterpret_cast<const uint2*>(&hs[(r + k) * BT_W + 4 * gx]);
-            uint32_t t = (uint32_t)tabs.taps[k];
-            s[0] += t * (h.x & 0xFFFFu);
-            s[1] += t * (h.x >> 16);
-            s[2] += t * (h.y & 0xFFFFu);
-            s[3] += t * (h.y >> 16);
-        }
-        uint32_t packed = 0;
+    for (int it = 0; it < 2; ++it) {
+        int item = tid + 256 * it, op = item >> 4, gx = item & 15;
+        int X = x0 + 4 * gx, Y = y0 + 2 * op;
+        if (op >= BT_H / 2 || X >= L.w || Y >= L.h) continue;
+        uint4 p0 = *reinterpret_cast<const uint4*>(&hs[(op + 0) * BT_W + 4 * gx]);
+        uint4 p1 = *reinterpret_cast<const uint4*>(&hs[(op + 1) * BT_W + 4 * gx]);
+        uint4 p2 = *reinterpret_cast<const uint4*>(&hs[(op + 2) * BT_W + 4 * gx]);
+        uint4 p3 = *reinterpret_cast<const uint4*>(&hs[(op + 3) * BT_W + 4 * gx]);
+        const uint32_t c0[4] = {p0.x, p0.y, p0.z, p0.w}, c1[4] = {p1.x, p1.y, p1.z, p1.w};
+        const uint32_t c2[4] = {p2.x, p2.y, p2.z, p2.w}, c3[4] = {p3.x, p3.y, p3.z, p3.w};
+        uint32_t se[4], so[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint32_t q = s[j] >> 16, rem = s[j] & 0xFFFFu;
-            uint32_t v = (X + j) < vec_end ? q + ((rem > 32768u) || (rem == 32768u && (q & 1u))) : (s[j] + 32768u) >> 16;
-            packed |= min(v, 255u) << (8 * j);
+            se[j] = udot2_u16(c0[j], ke0, udot2_u16(c1[j], ke1, udot2_u16(c2[j], ke2, udot2_u16(c3[j], ke3, 0u))));
+            so[j] = udot2_u16(c0[j], ko0, udot2_u16(c1[j], ko1, udot2_u16(c2[j], ko2, udot2_u16(c3[j], ko3, 0u))));
+            // sum / 65536 rounded half-to-even below vec_end, half-up from there on
+            uint32_t ev = (X + j) < vec_end ? 1u : 0u;
+            se[j] += 32768u - ev + (ev & (se[j] >> 16));
+            so[j] += 32768u - ev + (ev & (so[j] >> 16));
         }
+        // high halves -> i16 pairs -> saturated bytes
+        uint32_t e01 = sat_pk_u8_i16(__builtin_amdgcn_perm(se[1], se[0], 0x07060302u));
+        uint32_t e23 = sat_pk_u8_i16(__builtin_amdgcn_perm(se[3], se[2], 0x07060302u));
+        uint32_t o01 = sat_pk_u8_i16(__builtin_amdgcn_perm(so[1], so[0], 0x07060302u));
+        uint32_t o23 = sat_pk_u8_i16(__builtin_amdgcn_perm(so[3], so[2], 0x07060302u));
         // the row pitch is a multiple of 64, so the dword store stays inside the row even when
         // the level width is not a multiple of 4 (the surplus bytes are never read as pixels)
-        *reinterpret_cast<uint32_t*>(out + (size_t)Y * L.pitch + X) = packed;
+        *reinterpret_cast<uint32_t*>(out + (size_t)Y * L.pitch + X) = e01 | (e23 << 16);
+        if (Y + 1 < L.h) *reinterpret_cast<uint32_t*>(out + (size_t)(Y + 1) * L.pitch + X) = o01 | (o23 << 16);
     }
 }
 
