@@ -30,6 +30,8 @@ struct LevelGeom {
     int fast_tx, fast_ty, fast_tile0;   // FAST tile grid of the level and first flat tile id
     int blur_tx, blur_ty, blur_tile0;
     uint32_t xtab, ytab; // offsets into the resize coefficient table (levels >= 1)
+    uint32_t gtab;       // offset of the per-column-group table (12 dwords per four output columns)
+    uint32_t ncg, ncg_magic;   // column groups per row and ceil(2^32 / ncg)
 };
 
 struct Geom {

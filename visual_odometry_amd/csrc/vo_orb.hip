@@ -39,64 +39,99 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 va, vb;
+    __builtin_memcpy(&va, &a, 4);
+    __builtin_memcpy(&vb, &b, 4);
+    return __builtin_amdgcn_udot2(va, vb, c, false);
+}
+
 // ------------------------------------------------------------------ resize
 // Level l from level l-1, INTER_LINEAR_EXACT semantics: 8.8 coefficients,
-// out = (m0*(c0*a + c1*b) + m1*(c0*c + c1*d) + 2^15) >> 16.
-// Table entry = (source offset << 16) | c1, c0 = 256 - c1.
+// out = (m0*(c0*a + c1*b) + m1*(c0*c + c1*d) + 2^15) >> 16  (never above 255, the weights
+// sum to 2^16).  Row/column table entry = (source offset << 16) | c1, c0 = 256 - c1.
+// A lane produces 4 columns x RS_ROWS rows.  Its four columns read at most eight
+// consecutive source bytes per row (two unaligned dwords); the group table holds, per
+// column, a v_perm selector that places the two neighbours in the halves of a dword and
+// the coefficient pair (c0 | c1 << 16), so a horizontal interpolation is one v_perm and
+// one v_dot2_u32_u16 and the vertical one two 24-bit multiply-adds.
+constexpr int RS_ROWS = 4;
 __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_t* __restrict__ in,
                                                      uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab) {
     const LevelGeom& D = g.L[l];
     const LevelGeom& S = g.L[l - 1];
-    int img = blockIdx.z;
-    int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= D.h || x4 >= D.w) return;
+    const int img = blockIdx.y;
+    const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t rg = __umulhi(item, D.ncg_magic), cg = item - rg * D.ncg;
+    const int ybase = (int)rg * RS_ROWS, x4 = (int)cg * 4;
+    if (ybase >= D.h) return;
     int spitch;
     const uint8_t* src = level_base(g, in, pyr, img, l - 1, &spitch);
-    uint8_t* dst = pyr + (size_t)img * g.blk_stride + D.off + (size_t)y * D.pitch;
-    uint32_t ty = tab[D.ytab + y];
-    int sy = ty >> 16;
-    uint32_t m1 = ty & 0xFFFF, m0 = 256 - m1;
-    int sy1 = min(sy + 1, S.h - 1);
-    const uint8_t* r0 = src + (size_t)sy * spitch;
-    const uint8_t* r1 = src + (size_t)sy1 * spitch;
-    uint32_t tx[4];
+    uint8_t* dst = pyr + (size_t)img * g.blk_stride + D.off;
+    const uint32_t* gt = tab + D.gtab + 12 * cg;
+    const uint32_t head = gt[0];
+    const int sx0 = (int)(head & 0xFFFFu);
+    uint32_t ty[RS_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) tx[k] = tab[D.xtab + min(x4 + k, D.w - 1)];
-    // The four outputs read source columns sx0 .. sx0+6 at most (scale 1.2): fetch eight
-    // bytes per row with two unaligned dword loads when that stays inside the row.
-    int sx0 = tx[0] >> 16;
-    uint32_t outw = 0;
-    if (sx0 + 8 <= S.w) {
-        unsigned long long a = load_u32_unaligned(r0 + sx0) | ((unsigned long long)load_u32_unaligned(r0 + sx0 + 4) << 32);
-        unsigned long long b = load_u32_unaligned(r1 + sx0) | ((unsigned long long)load_u32_unaligned(r1 + sx0 + 4) << 32);
+    for (int j = 0; j < RS_ROWS; ++j) ty[j] = tab[D.ytab + min(ybase + j, D.h - 1)];
+    if (!(head >> 31)) {
+        const uint4 sel = *reinterpret_cast<const uint4*>(gt + 4), cf = *reinterpret_cast<const uint4*>(gt + 8);
+        uint32_t a[RS_ROWS][2], b[RS_ROWS][2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int o = (int)(tx[k] >> 16) - sx0;   // 0..5
-            uint32_t c1 = tx[k] & 0xFFFF, c0 = 256 - c1;
-            uint32_t a0 = (uint32_t)(a >> (8 * o)) & 0xFFu, a1 = (uint32_t)(a >> (8 * o + 8)) & 0xFFu;
-            uint32_t b0 = (uint32_t)(b >> (8 * o)) & 0xFFu, b1 = (uint32_t)(b >> (8 * o + 8)) & 0xFFu;
-            uint32_t h0 = c0 * a0 + c1 * a1;
-            uint32_t h1 = c0 * b0 + c1 * b1;
-            uint32_t v = min((m0 * h0 + m1 * h1 + 32768u) >> 16, 255u);
-            outw |= v << (8 * k);
+        for (int j = 0; j < RS_ROWS; ++j) {
+            int sy = ty[j] >> 16, sy1 = min(sy + 1, S.h - 1);
+            const uint8_t* r0 = src + (size_t)sy * spitch + sx0;
+            const uint8_t* r1 = src + (size_t)sy1 * spitch + sx0;
+            a[j][0] = load_u32_unaligned(r0);
+            a[j][1] = load_u32_unaligned(r0 + 4);
+            b[j][0] = load_u32_unaligned(r1);
+            b[j][1] = load_u32_unaligned(r1 + 4);
+        }
+        const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w}, cc[4] = {cf.x, cf.y, cf.z, cf.w};
+#pragma unroll
+        for (int j = 0; j < RS_ROWS; ++j) {
+            const uint32_t m1 = ty[j] & 0xFFFFu, m0 = 256u - m1;
+            uint32_t sum[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(a[j][1], a[j][0], sl[k]), cc[k], 0u);
+                uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(b[j][1], b[j][0], sl[k]), cc[k], 0u);
+                sum[k] = __umul24(m1, h1) + (__umul24(m0, h0) + 32768u);
+            }
+            uint32_t outw = __builtin_amdgcn_perm(sum[1], sum[0], 0x0C0C0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020C0Cu);
+            // pitch is a multiple of 64: the dword store stays inside the row
+            if (ybase + j < D.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(ybase + j) * D.pitch + x4) = outw;
         }
     } else {
+        // groups at the right edge (or with an unusual column spacing): byte loads
+        uint32_t tx[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t v = 0;
-            if (x4 + k < D.w) {
-                int sx = tx[k] >> 16;
-                uint32_t c1 = tx[k] & 0xFFFF, c0 = 256 - c1;
-                int sx1 = min(sx + 1, S.w - 1);
-                uint32_t h0 = c0 * r0[sx] + c1 * r0[sx1];
-                uint32_t h1 = c0 * r1[sx] + c1 * r1[sx1];
-                v = min((m0 * h0 + m1 * h1 + 32768u) >> 16, 255u);
+        for (int k = 0; k < 4; ++k) tx[k] = tab[D.xtab + min(x4 + k, D.w - 1)];
+#pragma unroll
+        for (int j = 0; j < RS_ROWS; ++j) {
+            if (ybase + j >= D.h) break;
+            int sy = ty[j] >> 16, sy1 = min(sy + 1, S.h - 1);
+            const uint32_t m1 = ty[j] & 0xFFFFu, m0 = 256u - m1;
+            const uint8_t* r0 = src + (size_t)sy * spitch;
+            const uint8_t* r1 = src + (size_t)sy1 * spitch;
+            uint32_t outw = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = 0;
+                if (x4 + k < D.w) {
+                    int sx = tx[k] >> 16;
+                    uint32_t c1 = tx[k] & 0xFFFF, c0 = 256 - c1;
+                    int sx1 = min(sx + 1, S.w - 1);
+                    uint32_t h0 = c0 * r0[sx] + c1 * r0[sx1];
+                    uint32_t h1 = c0 * r1[sx] + c1 * r1[sx1];
+                    v = (m0 * h0 + m1 * h1 + 32768u) >> 16;
+                }
+                outw |= v << (8 * k);
             }
-            outw |= v << (8 * k);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(ybase + j) * D.pitch + x4) = outw;
         }
     }
-    *reinterpret_cast<uint32_t*>(dst + x4) = outw;  // pitch is a multiple of 64: the store stays inside the row
 }
 
 // ------------------------------------------------------------------ FAST
@@ -578,14 +613,6 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v) {   // two i16 -> 
     return r;
 }
 
-__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    u16x2 va, vb;
-    __builtin_memcpy(&va, &a, 4);
-    __builtin_memcpy(&vb, &b, 4);
-    return __builtin_amdgcn_udot2(va, vb, c, false);
-}
-
 // Tile = 64 x 58 outputs from 64 source rows (3-row halo), 256 lanes.
 // Row pass: a lane takes two vertically adjacent source rows and four columns; each row
 // sum is two v_dot4_u32_u8 on byte-aligned windows (v_alignbyte) of three source dwords,
@@ -971,6 +998,25 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
                 L.ytab = (uint32_t)tab.size();
                 tab.resize(tab.size() + L.h);
                 lin_table(n.L[l - 1].h, L.h, &tab[L.ytab]);
+                tab.resize(align_up(tab.size(), 4));
+                L.ncg = (uint32_t)(L.w + 3) / 4;
+                L.ncg_magic = (uint32_t)((0x100000000ull + L.ncg - 1) / L.ncg);
+                L.gtab = (uint32_t)tab.size();
+                tab.resize(tab.size() + 12 * (size_t)L.ncg, 0u);
+                for (uint32_t cg = 0; cg < L.ncg; ++cg) {
+                    uint32_t* e = &tab[L.gtab + 12 * (size_t)cg];
+                    int sx0 = (int)(tab[L.xtab + 4 * cg] >> 16);
+                    bool fast = 4 * (int)cg + 3 < L.w && sx0 + 8 <= n.L[l - 1].w;
+                    for (int k = 0; k < 4 && fast; ++k) {
+                        uint32_t t = tab[L.xtab + 4 * cg + k];
+                        int o = (int)(t >> 16) - sx0;
+                        uint32_t c1 = t & 0xFFFFu;
+                        if (o < 0 || o > 6) { fast = false; break; }
+                        e[4 + k] = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);
+                        e[8 + k] = (256u - c1) | (c1 << 16);
+                    }
+                    e[0] = (uint32_t)sx0 | (fast ? 0u : 0x80000000u);
+                }
             }
         }
         n.blk_stride = off;
@@ -1021,7 +1067,8 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     VO_HIP(c, hipMemsetAsync(c->flags.p, 0, 256, s));
     t_begin(c, VO_T_RESIZE);
     for (int l = 1; l < kLevels; ++l) {
-        dim3 grid((g.L[l].w + 255) / 256, (g.L[l].h + 3) / 4, N);
+        uint32_t items = g.L[l].ncg * (uint32_t)((g.L[l].h + RS_ROWS - 1) / RS_ROWS);
+        dim3 grid((items + 255) / 256, N);
         hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, s, g, l, d_imgs, (uint8_t*)c->pyr.p,
                            (const uint32_t*)c->tab.p);
     }
