@@ -14,6 +14,10 @@ static const int8_t h_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 __device__ __attribute__((aligned(16))) int8_t d_pattern[256 * 4];
+// Disc masks of the intensity-centroid pass: entry [t][hl] is the byte mask of the dword
+// that half-wave lane hl (row hl >> 3 of a four-row group, dword hl & 7 of the 32-byte row
+// window starting at x - 15) loads in step t (patch row 4t - 15 + (hl >> 3)).
+__device__ uint32_t d_angle_mask[8 * 32];
 static bool g_pattern_loaded[64] = {false};
 
 struct SmallTabs {
@@ -30,6 +34,19 @@ __device__ __forceinline__ const uint8_t* level_base(const Geom& g, const uint8_
     *pitch = g.L[l].pitch;
     return pyr + (size_t)img * g.blk_stride + g.L[l].off;
 }
+
+// Workgroups are handed to the eight XCDs round-robin by flat workgroup id, and every XCD
+// has its own L2.  This permutation gives XCD x the contiguous range
+// [x * ceil(total/8), (x+1) * ceil(total/8)) of logical work items, so neighbouring tiles and
+// the keypoints of one image share an L2 (halo rows and partially used 128-byte lines are
+// then fetched from memory once instead of once per XCD).  The launch uses
+// xcd_grid(total) workgroups; returns false for the padding ones.
+__device__ __forceinline__ bool xcd_remap(uint32_t total, uint32_t* logical) {
+    const uint32_t per = (total + 7u) >> 3;
+    *logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    return (blockIdx.x >> 3) < per && *logical < total;
+}
+static inline uint32_t xcd_grid(uint32_t total) { return ((total + 7u) >> 3) << 3; }
 
 // Four bytes at an arbitrary byte address (one global_load_dword; gfx950 global loads need
 // no alignment).
@@ -211,7 +228,10 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     __shared__ uint32_t list[FT_W * FT_H / 4];
     __shared__ uint32_t n1, n2, nlist, gbase;
 
-    const int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    uint32_t work;
+    if (!xcd_remap((uint32_t)g.fast_tiles * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)g.fast_tiles), tile = (int)(work - (uint32_t)img * (uint32_t)g.fast_tiles);
+    const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
 #pragma unroll
     for (int k = 0; k < kLevels; ++k) {
@@ -509,12 +529,16 @@ __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* _
     if (tid == 0) sel_cnt[img * kLevels + l] = M;
 }
 
-__global__ __launch_bounds__(256) void harris_kernel(Geom g, int cap, const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(256) void harris_kernel(Geom g, int cap, int bx, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint32_t* __restrict__ sel_keys,
                                                      const uint32_t* __restrict__ sel_cnt, float* __restrict__ sel_resp) {
-    int l = blockIdx.y, img = blockIdx.z;
-    int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t work;
+    if (!xcd_remap((uint32_t)bx * kLevels * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)(bx * kLevels));
+    const int rem = (int)(work - (uint32_t)img * (uint32_t)(bx * kLevels));
+    const int l = rem / bx;
+    const int i = (rem - l * bx) * 256 + threadIdx.x;
     if (i >= (int)sel_cnt[img * kLevels + l]) return;
     size_t o = ((size_t)img * kLevels + l) * cap + i;
     uint32_t k = sel_keys[o];
@@ -628,7 +652,10 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     static_assert(PH == 64, "row pass covers 32 row pairs in two sweeps of 256 lanes");
     __shared__ __attribute__((aligned(16))) uint8_t px[PH * PW];
     __shared__ __attribute__((aligned(16))) uint32_t hs[(PH / 2) * BT_W];
-    int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    uint32_t work;
+    if (!xcd_remap((uint32_t)g.blur_tiles * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)g.blur_tiles), tile = (int)(work - (uint32_t)img * (uint32_t)g.blur_tiles);
+    const int tid = threadIdx.x;
     int l = 0;
 #pragma unroll
     for (int k = 0; k < kLevels; ++k) {
@@ -782,11 +809,13 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
 }
 
 // Half a wavefront (32 lanes) per keypoint, two keypoints per wave, grid-stride over an
-// image's keypoints: the half-wave first computes the intensity-centroid angle (lane = column
-// of the 31-px disc), its first lane writes the final keypoint, then lane t evaluates tests
-// t, t+32, ..., t+224 and eight ballots give the 32 descriptor bytes (low word: first
-// keypoint, high word: second).
-__global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
+// image's keypoints.  Intensity-centroid angle: the half-wave sweeps the 31x31 disc in
+// eight steps of four rows, lane = (row of the step, dword of the 32-byte row window); a
+// step is one unaligned dword load, the disc byte mask and two v_dot4_u32_u8 (sum and
+// column-weighted sum), the row weight is applied to the row sum.  The first lane of the
+// half writes the final keypoint, then lane t evaluates tests t, t+32, ..., t+224 and eight
+// ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
+__global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
                                                        const uint8_t* __restrict__ pyr,
                                                        const uint8_t* __restrict__ blur,
                                                        const uint16_t* __restrict__ kp_x,
@@ -795,7 +824,9 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
                                                        const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
                                                        uint8_t* __restrict__ desc, int cap, int32_t* __restrict__ counts,
                                                        uint32_t* __restrict__ flags) {
-    const int img = blockIdx.y;
+    uint32_t work;
+    if (!xcd_remap((uint32_t)bx * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)bx), blk = (int)(work - (uint32_t)img * (uint32_t)bx);
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const uint32_t* cnt = kp_cnt + img * kLevels;
     int start[kLevels + 1];
@@ -803,16 +834,28 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
 #pragma unroll
     for (int k = 0; k < kLevels; ++k) start[k + 1] = start[k] + (int)cnt[k];
     const int total = start[kLevels];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         counts[img] = min(total, cap);
         if (total > cap) atomicOr(flags, 4u);
     }
     const int n = min(total, cap);
-    // this lane's eight tests are the same for every keypoint: fetch them once
+    // this lane's eight tests and disc masks are the same for every keypoint: fetch them once
     int pat[8];
+    uint32_t amask[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
-    for (int o2 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += gridDim.x * 8) {
+    for (int k = 0; k < 8; ++k) {
+        pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
+        amask[k] = d_angle_mask[k * 32 + hl];
+    }
+    const int rr = hl >> 3, dj = hl & 7;
+    const uint32_t wcol = 0x03020100u + 0x04040404u * (uint32_t)dj;   // window byte index = u + 15
+    const uint8_t* blur_img = blur + (size_t)img * g.blk_stride;
+    // blurred window of +-18 px around the keypoint (the rotated test points stay inside:
+    // the pattern's largest radius is 18.4), one per half-wave, rows padded to 40 bytes
+    constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 40;
+    __shared__ __attribute__((aligned(16))) uint8_t patch[8][DP_ROWS * DP_PITCH];
+    uint8_t* my_patch = patch[(threadIdx.x >> 6) * 2 + half];
+    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
         const bool live = o2 + half < n;          // an odd count leaves the last second half idle
         const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
         int l = 0, lstart = 0;
@@ -825,25 +868,46 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
         const LevelGeom& L = g.L[l];
         size_t ib = (size_t)img * g.kp_stride + L.kp_off + slot;
         int x = kp_x[ib], y = kp_y[ib];
+        // The window loads are issued first, together with the angle pass' loads: 37 rows of
+        // 40 bytes as ten sweeps of 4 rows x 8 dwords and three of 16 rows x 2 dwords.  All
+        // of it lies inside the level (31-px keypoint margin).  Gathering the 512 test points
+        // from global memory instead costs one L1 tag look-up per lane and test.
+        const float fx = (float)x * L.scale, fy = (float)y * L.scale;
+        const int pitch = L.pitch;
+        uint32_t pw[13];
+        if (desc) {
+            const float inv = 1.f / L.scale;
+            const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
+            const uint32_t org = L.off + (uint32_t)((cy - DP_R) * pitch + cx - DP_R);
+#pragma unroll
+            for (int t = 0; t < 10; ++t)
+                pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(min(4 * t + rr, DP_ROWS - 1) * pitch + 4 * dj)));
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                pw[10 + t] = load_u32_unaligned(
+                    blur_img + (org + (uint32_t)(min(16 * t + (hl >> 1), DP_ROWS - 1) * pitch + 32 + 4 * (hl & 1))));
+        }
         float angle;
         {
             int lpitch;
             const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
-            const int u = hl - kHalfPatch, au = u < 0 ? -u : u;      // lane 31: u = 16, masked out
-            const uint8_t* col = lbase + (size_t)y * lpitch + x + u;
             // every address within 16 px of a keypoint is inside the level (keypoints keep a
-            // 31-px margin): all 31 loads are issued unconditionally and masked afterwards
-            int vals[2 * kHalfPatch + 1];
+            // 31-px margin): all loads are issued unconditionally and masked afterwards
+            const uint8_t* p = lbase + (size_t)(y - kHalfPatch + rr) * lpitch + (x - kHalfPatch + 4 * dj);
+            uint32_t v[8];
 #pragma unroll
-            for (int r = -kHalfPatch; r <= kHalfPatch; ++r) vals[r + kHalfPatch] = col[r * lpitch];
-            int m10 = 0, m01 = 0;
+            for (int t = 0; t < 8; ++t) v[t] = load_u32_unaligned(p + (size_t)(4 * t) * lpitch);
+            uint32_t S = 0, X = 0;
+            int m01 = 0;
 #pragma unroll
-            for (int r = -kHalfPatch; r <= kHalfPatch; ++r) {
-                int val = au <= tabs.umax[r < 0 ? -r : r] ? vals[r + kHalfPatch] : 0;
-                m10 += val;
-                m01 += r * val;
+            for (int t = 0; t < 8; ++t) {
+                uint32_t val = v[t] & amask[t];
+                uint32_t rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
+                X = __builtin_amdgcn_udot4(val, wcol, X, false);
+                S += rs;
+                m01 += (4 * t - kHalfPatch + rr) * (int)rs;
             }
-            m10 *= u;
+            int m10 = (int)X - kHalfPatch * (int)S;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) {
                 m10 += __shfl_xor(m10, o);
@@ -851,7 +915,6 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
             }
             angle = fast_atan2_deg((float)m01, (float)m10);
         }
-        float fx = (float)x * L.scale, fy = (float)y * L.scale;
         if (hl == 0 && live) {
             vo_keypoint k;
             k.x = fx;
@@ -864,14 +927,22 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
             kps[(size_t)img * cap + oi] = k;
         }
         if (!desc) continue;
-        float inv = 1.f / L.scale;
-        int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
         float ar = angle * (float)(M_PI / 180.f);
         double sd, cd;
         sincos_f64((double)ar, &sd, &cd);
         float a = (float)cd, b = (float)sd;
-        const uint8_t* center = blur + (size_t)img * g.blk_stride + L.off + (size_t)cy * L.pitch + cx;
-        const int pitch = L.pitch;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous keypoint's reads are done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 10; ++t)
+            if (4 * t + rr < DP_ROWS) *reinterpret_cast<uint32_t*>(&my_patch[(4 * t + rr) * DP_PITCH + 4 * dj]) = pw[t];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (16 * t + (hl >> 1) < DP_ROWS)
+                *reinterpret_cast<uint32_t*>(&my_patch[(16 * t + (hl >> 1)) * DP_PITCH + 32 + 4 * (hl & 1)]) = pw[10 + t];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* centre = my_patch + DP_R * DP_PITCH + DP_R;
         int t0[8], t1[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -879,8 +950,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, SmallTabs tabs, c
             float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
             float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
             float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-            t0[k] = center[__float2int_rn(ry0) * pitch + __float2int_rn(rx0)];
-            t1[k] = center[__float2int_rn(ry1) * pitch + __float2int_rn(rx1)];
+            t0[k] = centre[__float2int_rn(ry0) * DP_PITCH + __float2int_rn(rx0)];
+            t1[k] = centre[__float2int_rn(ry1) * DP_PITCH + __float2int_rn(rx1)];
         }
         uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
 #pragma unroll
@@ -1037,6 +1108,17 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
     g.n_images = n_images;
     if (!g_pattern_loaded[c->device]) {
         VO_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(d_pattern), h_pattern, sizeof(h_pattern)));
+        static const SmallTabs tabs = make_tabs();
+        std::vector<uint32_t> am(8 * 32, 0u);
+        for (int t = 0; t < 8; ++t)
+            for (int hl = 0; hl < 32; ++hl) {
+                int r = 4 * t - kHalfPatch + (hl >> 3);
+                for (int b = 0; b < 4 && r <= kHalfPatch; ++b) {
+                    int u = 4 * (hl & 7) + b - kHalfPatch;
+                    if (std::abs(u) <= tabs.umax[std::abs(r)]) am[t * 32 + hl] |= 0xFFu << (8 * b);
+                }
+            }
+        VO_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(d_angle_mask), am.data(), am.size() * 4));
         g_pattern_loaded[c->device] = true;
     }
     size_t N = (size_t)n_images;
@@ -1075,19 +1157,20 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     t_end(c, VO_T_RESIZE);
     if (g.fast_tiles > 0) {
         t_begin(c, VO_T_FAST);
-        hipLaunchKernelGGL(fast_kernel, dim3(g.fast_tiles, N), dim3(256), 0, s, g, d_imgs, pyr, (uint32_t*)c->cand.p,
+        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid((uint32_t)g.fast_tiles * N)), dim3(256), 0, s, g, d_imgs, pyr, (uint32_t*)c->cand.p,
                            (uint32_t*)c->cand_cnt.p);
         t_end(c, VO_T_FAST);
     }
     t_begin(c, VO_T_SELECT);
     int sel_need = 0;   // upper bound of a level's list after the first cut, for the Harris grid
     for (int l = 0; l < kLevels; ++l) sel_need = std::max(sel_need, std::min(g.sel_cap, g.L[l].cand_cap));
+    const int hbx = std::max((sel_need + 255) / 256, 1);
 #define VO_SELECT(CAPV)                                                                                              \
     do {                                                                                                             \
         hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
                            (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
                            (uint32_t*)c->flags.p);                                                                   \
-        hipLaunchKernelGGL(harris_kernel, dim3((sel_need + 255) / 256, kLevels, N), dim3(256), 0, s, g, CAPV, d_imgs, \
+        hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hbx * kLevels * N)), dim3(256), 0, s, g, CAPV, hbx, d_imgs, \
                            pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
         hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g,                              \
                            (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
@@ -1101,12 +1184,13 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     t_end(c, VO_T_SELECT);
     if (d_desc) {
         t_begin(c, VO_T_BLUR);
-        hipLaunchKernelGGL(blur_kernel, dim3(g.blur_tiles, N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
+        hipLaunchKernelGGL(blur_kernel, dim3(xcd_grid((uint32_t)g.blur_tiles * N)), dim3(256), 0, s, g, tabs, d_imgs, pyr,
                            (uint8_t*)c->blur.p);
         t_end(c, VO_T_BLUR);
     }
     t_begin(c, VO_T_DESCRIBE);
-    hipLaunchKernelGGL(describe_kernel, dim3(std::max((g.max_features + 7) / 8, 1), N), dim3(256), 0, s, g, tabs, d_imgs, pyr,
+    const int dbx = std::max((g.max_features + 31) / 32, 1);   // about four keypoint pairs per wavefront
+    hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
                        (const uint8_t*)c->blur.p, (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p,
                        (const float*)c->kp_resp.p, (const uint32_t*)c->kp_cnt.p, d_kps,
                        d_desc, cap, d_counts, (uint32_t*)c->flags.p);
