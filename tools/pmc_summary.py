@@ -6,11 +6,12 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 table = collections.defaultdict(dict)
 for d in sys.argv[1:]:
-    files = sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True))
+    files = sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     if not files:
         continue
     agg = collections.defaultdict(list)

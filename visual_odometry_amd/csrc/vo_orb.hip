@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
         uint32_t a[RS_ROWS][2], b[RS_ROWS][2];
 #pragma unroll
         for (int j = 0; j < RS_ROWS; ++j) {
-            int sy = ty[j] >> 16, sy1 = min(sy + 1, S.h - 1);
-            const uint8_t* r0 = src + (size_t)sy * spitch + sx0;
-            const uint8_t* r1 = src + (size_t)sy1 * spitch + sx0;
-            a[j][0] = load_u32_unaligned(r0);
-            a[j][1] = load_u32_unaligned(r0 + 4);
-            b[j][0] = load_u32_unaligned(r1);
-            b[j][1] = load_u32_unaligned(r1 + 4);
+            // 32-bit offsets from the wave-uniform image base (24-bit multiplies: rows and
+            // pitches are below 2^13)
+            uint32_t sy = ty[j] >> 16, sy1 = min(sy + 1u, (uint32_t)(S.h - 1));
+            uint32_t o0 = __umul24(sy, (uint32_t)spitch) + (uint32_t)sx0;
+            uint32_t o1 = __umul24(sy1, (uint32_t)spitch) + (uint32_t)sx0;
+            a[j][0] = load_u32_unaligned(src + o0);
+            a[j][1] = load_u32_unaligned(src + (o0 + 4u));
+            b[j][0] = load_u32_unaligned(src + o1);
+            b[j][1] = load_u32_unaligned(src + (o1 + 4u));
         }
         const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w}, cc[4] = {cf.x, cf.y, cf.z, cf.w};
 #pragma unroll
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
             }
             uint32_t outw = __builtin_amdgcn_perm(sum[1], sum[0], 0x0C0C0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020C0Cu);
             // pitch is a multiple of 64: the dword store stays inside the row
-            if (ybase + j < D.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(ybase + j) * D.pitch + x4) = outw;
+            if (ybase + j < D.h)
+                *reinterpret_cast<uint32_t*>(dst + (__umul24((uint32_t)(ybase + j), (uint32_t)D.pitch) + (uint32_t)x4)) = outw;
         }
     } else {
         // groups at the right edge (or with an unusual column spacing): byte loads
@@ -271,29 +274,60 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
 
-    // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed.
-    // Lane = column, wave = row phase, so the loop carries one pointer and one row counter;
-    // the two surplus columns (64, 65) are swept by a second, short pass.
-    const int cx0 = x0 - 1 - ax0;   // LDS column of score column 0
-    auto pretest = [&](const uint8_t* p) -> bool {
-        int v = p[0];
-        int d0 = v - (int)p[3 * FP_W], d4 = v - (int)p[3], d8 = v - (int)p[-3 * FP_W], d12 = v - (int)p[-3];
-        bool b0 = d0 > kFastThr, b4 = d4 > kFastThr, b8 = d8 > kFastThr, b12 = d12 > kFastThr;
-        bool k0 = d0 < -kFastThr, k4 = d4 < -kFastThr, k8 = d8 < -kFastThr, k12 = d12 < -kFastThr;
-        return (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0) | (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0);
-    };
+    // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed,
+    // four horizontally adjacent pixels per lane.  The even and the odd bytes of a dword sit
+    // in 16-bit fields; with K = 511 - thr in both fields, (centre + K) - ring has bit 9 of a
+    // field set iff centre - ring > thr and ring + (K - centre) iff ring - centre > thr (no
+    // carry crosses a field: all values stay in [236, 746]).  A 9-arc contains two adjacent
+    // cardinals, i.e. (S | N) & (E | W) for one polarity.
+    // LDS column of score column 0: x0 = kEdge + 64k, so (x0 - 4) & ~3 = x0 - 7 and x0 - 1 - ax0 = 6
+    static_assert(kEdge % 4 == 3 && FT_W % 4 == 0, "the score region starts at LDS column 6");
+    constexpr int cx0 = 6;
     const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
     {
-        const int sx = tid & 63;
-        const bool col_ok = sx <= max_sx;
-        for (int sy = tid >> 6; sy < FS_H; sy += 4) {
-            bool pass = col_ok && sy <= max_sy && pretest(&px[(sy + 3) * FP_W + cx0 + sx]);
-            wave_push(pass, (uint16_t)(sy * (FT_W + 2) + sx), q1, &n1, lane);
-        }
-        if (tid < 128) {   // waves 0 and 1, whole waves: columns 64 and 65
-            const int sx2 = FT_W + (tid >> 6), sy = tid & 63;
-            bool pass = sy < FS_H && sx2 <= max_sx && sy <= max_sy && pretest(&px[(min(sy, FS_H - 1) + 3) * FP_W + cx0 + sx2]);
-            wave_push(pass, (uint16_t)(sy * (FT_W + 2) + sx2), q1, &n1, lane);
+        constexpr int PD = FP_W / 4;   // dwords per LDS row
+        const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
+        constexpr int g0 = cx0 >> 2, ng = ((cx0 + FT_W + 1) >> 2) - g0 + 1;
+        const int lim_x = min(FT_W + 1, max_sx), lim_y = min(FS_H - 1, max_sy);
+        constexpr uint32_t KK = (uint32_t)(511 - kFastThr) * 0x00010001u, EV = 0x00FF00FFu, FL = 0x02000200u;
+        for (int i0 = 0; i0 < ng * FS_H; i0 += 256) {
+            const int i = i0 + tid;
+            const int sy = i / ng, gi = g0 + (i - sy * ng);
+            uint32_t T = 0;   // bits 9, 10, 25, 26: pixels 0..3 of the group pass
+            if (sy <= lim_y) {
+                const int idx = (sy + 3) * PD + gi;
+                const uint32_t C = px32[idx], Lw = px32[idx - 1], Rw = px32[idx + 1];
+                const uint32_t S = px32[idx + 3 * PD], N = px32[idx - 3 * PD];
+                const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1), E = __builtin_amdgcn_alignbyte(Rw, C, 3);
+                const uint32_t Ce = C & EV, Co = (C >> 8) & EV;
+                const uint32_t be = Ce + KK, de = KK - Ce, bo = Co + KK, dn = KK - Co;
+                const uint32_t Se = S & EV, So = (S >> 8) & EV, Ne = N & EV, No = (N >> 8) & EV;
+                const uint32_t Ee = E & EV, Eo = (E >> 8) & EV, We = W & EV, Wo = (W >> 8) & EV;
+                const uint32_t pe = (((be - Se) | (be - Ne)) & ((be - Ee) | (be - We))) |
+                                    (((Se + de) | (Ne + de)) & ((Ee + de) | (We + de)));
+                const uint32_t po = (((bo - So) | (bo - No)) & ((bo - Eo) | (bo - Wo))) |
+                                    (((So + dn) | (No + dn)) & ((Eo + dn) | (Wo + dn)));
+                T = (pe & FL) | ((po & FL) << 1);
+                // columns of the group that are score columns 0 .. lim_x
+                const int sx0 = 4 * gi - cx0;
+                const int lo = max(-sx0, 0), hi = min(lim_x - sx0 + 1, 4);
+                const uint32_t nib = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                T &= ((nib & 3u) << 9) | ((nib & 12u) << 23);
+            }
+            const unsigned long long m0 = __ballot(T & (1u << 9)), m1 = __ballot(T & (1u << 10));
+            const unsigned long long m2 = __ballot(T & (1u << 25)), m3 = __ballot(T & (1u << 26));
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
+            const uint32_t tot = c0 + c1 + c2 + (uint32_t)__popcll(m3);
+            if (tot == 0) continue;   // wave-uniform
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&n1, tot);
+            qb = __shfl(qb, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint16_t pos = (uint16_t)(sy * (FT_W + 2) + 4 * gi - cx0);
+            if (T & (1u << 9)) q1[qb + (uint32_t)__popcll(m0 & below)] = pos;
+            if (T & (1u << 10)) q1[qb + c0 + (uint32_t)__popcll(m1 & below)] = (uint16_t)(pos + 1);
+            if (T & (1u << 25)) q1[qb + c0 + c1 + (uint32_t)__popcll(m2 & below)] = (uint16_t)(pos + 2);
+            if (T & (1u << 26)) q1[qb + c0 + c1 + c2 + (uint32_t)__popcll(m3 & below)] = (uint16_t)(pos + 3);
         }
     }
     __syncthreads();
@@ -855,45 +889,62 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
     constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 40;
     __shared__ __attribute__((aligned(16))) uint8_t patch[8][DP_ROWS * DP_PITCH];
     uint8_t* my_patch = patch[(threadIdx.x >> 6) * 2 + half];
-    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
-        const bool live = o2 + half < n;          // an odd count leaves the last second half idle
-        const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
-        int l = 0, lstart = 0;
+    // keypoint o -> (level, slot in the level's list); the coordinates of the next round's
+    // keypoint are fetched one round ahead
+    auto locate = [&](int o2, bool* live, int* oi, int* l) -> size_t {
+        *live = o2 + half < n;                 // an odd count leaves the last second half idle
+        *oi = *live ? o2 + half : min(o2, max(n - 1, 0));   // (it repeats a neighbour's work, writes nothing)
+        int lv = 0, lstart = 0;
 #pragma unroll
         for (int k = 1; k < kLevels; ++k) {
-            l += (oi >= start[k]);
-            lstart = (oi >= start[k]) ? start[k] : lstart;
+            lv += (*oi >= start[k]);
+            lstart = (*oi >= start[k]) ? start[k] : lstart;
         }
-        const int slot = oi - lstart;
-        const LevelGeom& L = g.L[l];
-        size_t ib = (size_t)img * g.kp_stride + L.kp_off + slot;
-        int x = kp_x[ib], y = kp_y[ib];
+        *l = lv;
+        return (size_t)img * g.kp_stride + g.L[lv].kp_off + (*oi - lstart);
+    };
+    int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2;
+    if (o2 >= n) return;
+    bool live;
+    int oi, l;
+    size_t ib = locate(o2, &live, &oi, &l);
+    int x = kp_x[ib], y = kp_y[ib];
+    for (; o2 < n; o2 += bx * 8) {
+        const bool live_c = live;
+        const int oi_c = oi, l_c = l, x_c = x, y_c = y;
+        const size_t ib_c = ib;
+        if (o2 + bx * 8 < n) {   // wave-uniform
+            ib = locate(o2 + bx * 8, &live, &oi, &l);
+            x = kp_x[ib];
+            y = kp_y[ib];
+        }
+        const LevelGeom& L = g.L[l_c];
         // The window loads are issued first, together with the angle pass' loads: 37 rows of
         // 40 bytes as ten sweeps of 4 rows x 8 dwords and three of 16 rows x 2 dwords.  All
         // of it lies inside the level (31-px keypoint margin).  Gathering the 512 test points
         // from global memory instead costs one L1 tag look-up per lane and test.
-        const float fx = (float)x * L.scale, fy = (float)y * L.scale;
+        const float fx = (float)x_c * L.scale, fy = (float)y_c * L.scale;
         const int pitch = L.pitch;
         uint32_t pw[13];
         if (desc) {
             const float inv = 1.f / L.scale;
             const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-            const uint32_t org = L.off + (uint32_t)((cy - DP_R) * pitch + cx - DP_R);
+            const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R);
 #pragma unroll
             for (int t = 0; t < 10; ++t)
-                pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(min(4 * t + rr, DP_ROWS - 1) * pitch + 4 * dj)));
+                pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(__mul24(min(4 * t + rr, DP_ROWS - 1), pitch) + 4 * dj)));
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 pw[10 + t] = load_u32_unaligned(
-                    blur_img + (org + (uint32_t)(min(16 * t + (hl >> 1), DP_ROWS - 1) * pitch + 32 + 4 * (hl & 1))));
+                    blur_img + (org + (uint32_t)(__mul24(min(16 * t + (hl >> 1), DP_ROWS - 1), pitch) + 32 + 4 * (hl & 1))));
         }
         float angle;
         {
             int lpitch;
-            const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
+            const uint8_t* lbase = level_base(g, in, pyr, img, l_c, &lpitch);
             // every address within 16 px of a keypoint is inside the level (keypoints keep a
             // 31-px margin): all loads are issued unconditionally and masked afterwards
-            const uint8_t* p = lbase + (size_t)(y - kHalfPatch + rr) * lpitch + (x - kHalfPatch + 4 * dj);
+            const uint8_t* p = lbase + (size_t)(y_c - kHalfPatch + rr) * lpitch + (x_c - kHalfPatch + 4 * dj);
             uint32_t v[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[t] = load_u32_unaligned(p + (size_t)(4 * t) * lpitch);
@@ -915,16 +966,16 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             }
             angle = fast_atan2_deg((float)m01, (float)m10);
         }
-        if (hl == 0 && live) {
+        if (hl == 0 && live_c) {
             vo_keypoint k;
             k.x = fx;
             k.y = fy;
             k.size = 31 * L.scale;
             k.angle = angle;
-            k.response = kp_resp[ib];
-            k.octave = l;
+            k.response = kp_resp[ib_c];
+            k.octave = l_c;
             k.class_id = -1;
-            kps[(size_t)img * cap + oi] = k;
+            kps[(size_t)img * cap + oi_c] = k;
         }
         if (!desc) continue;
         float ar = angle * (float)(M_PI / 180.f);
@@ -950,8 +1001,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
             float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
             float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-            t0[k] = centre[__float2int_rn(ry0) * DP_PITCH + __float2int_rn(rx0)];
-            t1[k] = centre[__float2int_rn(ry1) * DP_PITCH + __float2int_rn(rx1)];
+            t0[k] = centre[__mul24(__float2int_rn(ry0), DP_PITCH) + __float2int_rn(rx0)];
+            t1[k] = centre[__mul24(__float2int_rn(ry1), DP_PITCH) + __float2int_rn(rx1)];
         }
         uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
 #pragma unroll
@@ -960,7 +1011,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
             if (hl == k) mine = w;
         }
-        if (hl < 8 && live) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi) * 32 + hl * 4) = mine;
+        if (hl < 8 && live_c) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi_c) * 32 + hl * 4) = mine;
     }
 }
 
@@ -1075,18 +1126,23 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
                 L.gtab = (uint32_t)tab.size();
                 tab.resize(tab.size() + 12 * (size_t)L.ncg, 0u);
                 for (uint32_t cg = 0; cg < L.ncg; ++cg) {
+                    // eight source bytes starting at `base` cover the group's four columns; at the
+                    // right edge the window is pulled back inside the row (a neighbour that would
+                    // fall outside it always has weight 0), columns past the level width repeat
+                    // the last one (they land in the row padding)
                     uint32_t* e = &tab[L.gtab + 12 * (size_t)cg];
-                    int sx0 = (int)(tab[L.xtab + 4 * cg] >> 16);
-                    bool fast = 4 * (int)cg + 3 < L.w && sx0 + 8 <= n.L[l - 1].w;
+                    const int sw = n.L[l - 1].w;
+                    int base = std::min((int)(tab[L.xtab + 4 * cg] >> 16), sw - 8);
+                    bool fast = sw >= 8;
                     for (int k = 0; k < 4 && fast; ++k) {
-                        uint32_t t = tab[L.xtab + 4 * cg + k];
-                        int o = (int)(t >> 16) - sx0;
+                        uint32_t t = tab[L.xtab + std::min<int>(4 * cg + k, L.w - 1)];
+                        int o = (int)(t >> 16) - base;
                         uint32_t c1 = t & 0xFFFFu;
-                        if (o < 0 || o > 6) { fast = false; break; }
-                        e[4 + k] = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);
+                        if (o < 0 || o > 7 || (o == 7 && c1 != 0)) { fast = false; break; }
+                        e[4 + k] = 0x0C000C00u | (uint32_t)o | ((uint32_t)std::min(o + 1, 7) << 16);
                         e[8 + k] = (256u - c1) | (c1 << 16);
                     }
-                    e[0] = (uint32_t)sx0 | (fast ? 0u : 0x80000000u);
+                    e[0] = (uint32_t)std::max(base, 0) | (fast ? 0u : 0x80000000u);
                 }
             }
         }

@@ -114,7 +114,8 @@ __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------ five-point solver
-constexpr int ST = 64;   // lanes per solve workgroup (one hypothesis each)
+constexpr int ST = 16;   // lanes per solve workgroup (one hypothesis each): 25 KB of LDS, so a workgroup fits
+                         // beside the resident tiles of a concurrently running image kernel
 
 // quad[10] (+)= s * a[4] (x) b[4]
 __host__ __device__ __forceinline__ void mul_ll(const double* a, const double* b, double s, double* q) {
