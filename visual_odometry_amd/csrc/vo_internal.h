@@ -43,6 +43,9 @@ struct Geom {
     int cand_stride;      // candidate entries per image
     int kp_stride;        // selected-keypoint entries per image
     int fast_tiles, blur_tiles;
+    // per-tile (level << 24 | tile row << 12 | tile column) tables inside the resize table buffer,
+    // and floor(2^32 / tiles) for the workgroup -> (image, tile) split
+    uint32_t fast_ttab, blur_ttab, fast_magic, blur_magic;
     int max_features;
     int sel_cap;          // LDS list capacity chosen for the select kernel
 };

@@ -48,6 +48,18 @@ __device__ __forceinline__ bool xcd_remap(uint32_t total, uint32_t* logical) {
 }
 static inline uint32_t xcd_grid(uint32_t total) { return ((total + 7u) >> 3) << 3; }
 
+// work = img * tiles + tile with magic = floor(2^32 / tiles): the high product is the quotient
+// or one below it.  All operands are wave-uniform, so this stays on the scalar unit.
+__device__ __forceinline__ void split_work(uint32_t work, uint32_t tiles, uint32_t magic, int* img, int* tile) {
+    uint32_t q = __umulhi(work, magic), r = work - q * tiles;
+    if (r >= tiles) {
+        ++q;
+        r -= tiles;
+    }
+    *img = (int)q;
+    *tile = (int)r;
+}
+
 // Four bytes at an arbitrary byte address (one global_load_dword; gfx950 global loads need
 // no alignment).
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
@@ -223,8 +235,8 @@ __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, 
 //   3. the corner score (min/max ladder), written to an LDS score tile;
 // then 3x3 non-max suppression, the border filter and one global atomic per tile.
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
-                                                   const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cand_cnt) {
+                                                   const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
+                                                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t px[FP_H * FP_W];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
     __shared__ uint16_t q1[FQ_N], q2[FQ_N];
@@ -233,17 +245,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
 
     uint32_t work;
     if (!xcd_remap((uint32_t)g.fast_tiles * (uint32_t)g.n_images, &work)) return;
-    const int img = (int)(work / (uint32_t)g.fast_tiles), tile = (int)(work - (uint32_t)img * (uint32_t)g.fast_tiles);
+    int img, tile;
+    split_work(work, (uint32_t)g.fast_tiles, g.fast_magic, &img, &tile);
     const int tid = threadIdx.x, lane = tid & 63;
-    int l = 0;
-#pragma unroll
-    for (int k = 0; k < kLevels; ++k) {
-        int t0 = g.L[k].fast_tile0;
-        if (tile >= t0 && tile < t0 + g.L[k].fast_tx * g.L[k].fast_ty) l = k;
-    }
+    const uint32_t te = tab[g.fast_ttab + tile];
+    const int l = (int)(te >> 24);
     const LevelGeom& L = g.L[l];
-    int tl = tile - L.fast_tile0;
-    int x0 = kEdge + (tl % L.fast_tx) * FT_W, y0 = kEdge + (tl / L.fast_tx) * FT_H;
+    int x0 = kEdge + (int)(te & 0xFFFu) * FT_W, y0 = kEdge + (int)((te >> 12) & 0xFFFu) * FT_H;
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
     int ax0 = (x0 - 4) & ~3;   // LDS column 0 <-> image column ax0
@@ -681,24 +689,21 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v) {   // two i16 -> 
 // taps paired (t0,t1)(t2,t3)(t4,t5)(t6,0) for the even row and (0,t0)(t1,t2)(t3,t4)(t5,t6)
 // for the odd one.
 __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const uint8_t* __restrict__ in,
-                                                   const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+                                                   const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
+                                                   uint8_t* __restrict__ blur) {
     constexpr int PW = BT_W + 8, PH = BT_H + 6;          // LDS column 0 <-> image column x0 - 4
     static_assert(PH == 64, "row pass covers 32 row pairs in two sweeps of 256 lanes");
     __shared__ __attribute__((aligned(16))) uint8_t px[PH * PW];
     __shared__ __attribute__((aligned(16))) uint32_t hs[(PH / 2) * BT_W];
     uint32_t work;
     if (!xcd_remap((uint32_t)g.blur_tiles * (uint32_t)g.n_images, &work)) return;
-    const int img = (int)(work / (uint32_t)g.blur_tiles), tile = (int)(work - (uint32_t)img * (uint32_t)g.blur_tiles);
+    int img, tile;
+    split_work(work, (uint32_t)g.blur_tiles, g.blur_magic, &img, &tile);
     const int tid = threadIdx.x;
-    int l = 0;
-#pragma unroll
-    for (int k = 0; k < kLevels; ++k) {
-        int t0 = g.L[k].blur_tile0;
-        if (tile >= t0 && tile < t0 + g.L[k].blur_tx * g.L[k].blur_ty) l = k;
-    }
+    const uint32_t te = tab[g.blur_ttab + tile];
+    const int l = (int)(te >> 24);
     const LevelGeom& L = g.L[l];
-    int tl = tile - L.blur_tile0;
-    int x0 = (tl % L.blur_tx) * BT_W, y0 = (tl / L.blur_tx) * BT_H;
+    int x0 = (int)(te & 0xFFFu) * BT_W, y0 = (int)((te >> 12) & 0xFFFu) * BT_H;
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
     const bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
@@ -1146,6 +1151,16 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
                 }
             }
         }
+        n.fast_ttab = (uint32_t)tab.size();
+        for (int l = 0; l < kLevels; ++l)
+            for (int ty = 0; ty < n.L[l].fast_ty; ++ty)
+                for (int tx = 0; tx < n.L[l].fast_tx; ++tx) tab.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | (uint32_t)tx);
+        n.blur_ttab = (uint32_t)tab.size();
+        for (int l = 0; l < kLevels; ++l)
+            for (int ty = 0; ty < n.L[l].blur_ty; ++ty)
+                for (int tx = 0; tx < n.L[l].blur_tx; ++tx) tab.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | (uint32_t)tx);
+        n.fast_magic = ftile > 0 ? (uint32_t)std::min<unsigned long long>(0x100000000ull / (uint32_t)ftile, 0xFFFFFFFFull) : 0u;
+        n.blur_magic = btile > 0 ? (uint32_t)std::min<unsigned long long>(0x100000000ull / (uint32_t)btile, 0xFFFFFFFFull) : 0u;
         n.blk_stride = off;
         n.cand_stride = cand_off;
         n.kp_stride = kp_off;
@@ -1213,7 +1228,8 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     t_end(c, VO_T_RESIZE);
     if (g.fast_tiles > 0) {
         t_begin(c, VO_T_FAST);
-        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid((uint32_t)g.fast_tiles * N)), dim3(256), 0, s, g, d_imgs, pyr, (uint32_t*)c->cand.p,
+        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid((uint32_t)g.fast_tiles * N)), dim3(256), 0, s, g, d_imgs, pyr,
+                           (const uint32_t*)c->tab.p, (uint32_t*)c->cand.p,
                            (uint32_t*)c->cand_cnt.p);
         t_end(c, VO_T_FAST);
     }
@@ -1241,7 +1257,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     if (d_desc) {
         t_begin(c, VO_T_BLUR);
         hipLaunchKernelGGL(blur_kernel, dim3(xcd_grid((uint32_t)g.blur_tiles * N)), dim3(256), 0, s, g, tabs, d_imgs, pyr,
-                           (uint8_t*)c->blur.p);
+                           (const uint32_t*)c->tab.p, (uint8_t*)c->blur.p);
         t_end(c, VO_T_BLUR);
     }
     t_begin(c, VO_T_DESCRIBE);
