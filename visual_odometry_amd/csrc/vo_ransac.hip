@@ -449,7 +449,8 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
 // x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm
 // essential matrices (row-major) to Es.  sA: this lane's column of the
 // 10x20 elimination matrix in LDS (element (r,c) at sA[(r*20+c)*ST]).
-__host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
+__host__ __device__ bool five_point_front(const double* x1, const double* x2, double* sA, double (*EE)[9],
+                                          double (*bm)[13], double* cf) {
     // ---- null space of the 5x9 epipolar constraint matrix (Householder QR of its transpose)
     double M[9][5];
 #pragma unroll
@@ -481,7 +482,6 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
             for (int i = k; i < 9; ++i) M[i][j] -= dot * M[i][k];
         }
     }
-    double EE[4][9];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         double e[9];
@@ -575,7 +575,7 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
             double v = fabs(A_(r, k));
             if (v > best) { best = v; p = r; }
         }
-        if (!(best > 1e-300)) return 0;
+        if (!(best > 1e-300)) return false;
         double pr[20];
 #pragma unroll
         for (int c = k; c < 20; ++c) pr[c] = sA[(p * 20 + c) * ST];
@@ -600,7 +600,6 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     // rows 4..9 <-> x^2 z, x^2, y^2 z, y^2, x y z, x y; columns 10..19 <->
     // x z^2, x z, x, y z^2, y z, y, z^3, z^2, z, 1.
     // z*row(m) - row(m z):  x*p3(z) + y*q3(z) + r4(z) = 0, stored descending.
-    double bm[3][13];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -620,7 +619,6 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     }
 #undef A_
     // ---- determinant polynomial (degree 10, ascending coefficients)
-    double cf[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) cf[i] = 0;
     {
@@ -655,13 +653,54 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
                     if (i + j <= 10) cf[i + j] += sgn[p] * (t01[i] * f[2][perm[p][2]][j]);
         }
     }
+    double cmax = 0;
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
+    return cmax > 0 && cmax < DBL_MAX;
+}
+
+// Start values of one candidate: (x, y) from the null vector of the 3x3 system at the root
+// z (best-conditioned row cross product).  Returns false when there is none.
+__host__ __device__ __forceinline__ bool model_start(const double (*bm)[13], double z1, double* x, double* y) {
+    double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    double bz[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bz[j][0] = bm[j][0] * z3 + bm[j][1] * z2 + bm[j][2] * z1 + bm[j][3];
+        bz[j][1] = bm[j][4] * z3 + bm[j][5] * z2 + bm[j][6] * z1 + bm[j][7];
+        bz[j][2] = bm[j][8] * z4 + bm[j][9] * z3 + bm[j][10] * z2 + bm[j][11] * z1 + bm[j][12];
+    }
+    double bx = 0, by = 0, bw = 0, bn = -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int r0 = a == 2 ? 1 : 0, r1 = a == 0 ? 1 : 2;
+        double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
+        double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
+        double cw = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
+        double nn = cx * cx + cy * cy + cw * cw;
+        if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
+    }
+    if (!(bn > 0)) return false;
+    double inv = 1.0 / sqrt(bn);
+    bx *= inv; by *= inv; bw *= inv;
+    if (fabs(bw) < 1e-10) return false;
+    *x = bx / bw;
+    *y = by / bw;
+    return true;
+}
+
+// x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm essential matrices
+// (row-major) to Es.  One lane does everything (host harness; the device path splits the
+// root search and the refinement over sixteen lanes, see solve_hypotheses).
+__host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
+    double EE[4][9], bm[3][13], cf[11];
+    if (!five_point_front(x1, x2, sA, EE, bm, cf)) return 0;
     // the elimination matrix is no longer needed: its LDS column becomes the root lists
     int nr;
     {
         double cmax = 0;
 #pragma unroll
         for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
-        if (!(cmax > 0) || !(cmax < DBL_MAX)) return 0;
         if (fabs(cf[10]) > 1e-14 * cmax) {
             nr = real_roots10(cf, sA);
         } else {   // degree-deficient polynomial (rare): generic path
@@ -672,31 +711,10 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     }
     int count = 0;
     for (int ri = 0; ri < nr && count < kMaxModels; ++ri) {
-        double z1 = sA[ri * ST], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
-        double bz[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            bz[j][0] = bm[j][0] * z3 + bm[j][1] * z2 + bm[j][2] * z1 + bm[j][3];
-            bz[j][1] = bm[j][4] * z3 + bm[j][5] * z2 + bm[j][6] * z1 + bm[j][7];
-            bz[j][2] = bm[j][8] * z4 + bm[j][9] * z3 + bm[j][10] * z2 + bm[j][11] * z1 + bm[j][12];
-        }
-        // null vector of the (numerically singular) 3x3: best-conditioned row cross product
-        double bx = 0, by = 0, bw = 0, bn = -1;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            int r0 = a == 2 ? 1 : 0, r1 = a == 0 ? 1 : 2;
-            double cx = bz[r0][1] * bz[r1][2] - bz[r0][2] * bz[r1][1];
-            double cy = bz[r0][2] * bz[r1][0] - bz[r0][0] * bz[r1][2];
-            double cw = bz[r0][0] * bz[r1][1] - bz[r0][1] * bz[r1][0];
-            double nn = cx * cx + cy * cy + cw * cw;
-            if (nn > bn) { bn = nn; bx = cx; by = cy; bw = cw; }
-        }
-        if (!(bn > 0)) continue;
-        double inv = 1.0 / sqrt(bn);
-        bx *= inv; by *= inv; bw *= inv;
-        if (fabs(bw) < 1e-10) continue;
+        double z1 = sA[ri * ST], sx, sy;
+        if (!model_start(bm, z1, &sx, &sy)) continue;
         double Ev[9];
-        double res = polish_model_dev(EE, bx / bw, by / bw, z1, Ev);
+        double res = polish_model_dev(EE, sx, sy, z1, Ev);
         if (!(res <= 1e-9)) continue;   // did not settle on a solution
         bool dup = false;               // two starts that settled on the same solution
         for (int m = 0; m < count && !dup; ++m) {
@@ -716,27 +734,264 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     return count;
 }
 
-__global__ __launch_bounds__(ST) void solve_kernel(const RState* __restrict__ st, const double* __restrict__ m,
-                                                   int n_max, const int32_t* __restrict__ samples, int samples_stride,
-                                                   int h0, int hr, double* __restrict__ models,
-                                                   int32_t* __restrict__ nmodels) {
-    __shared__ double sA[200 * ST];
-    int b = blockIdx.y, h = blockIdx.x * ST + threadIdx.x;
-    const RState& s = st[b];
-    bool active = h < hr && !s.done && (h0 + h) < s.niters;
-    int nm = 0;
-    if (active) {
-        const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
-        double x1[10], x2[10];
+// ---- sixteen lanes per hypothesis: root search and refinement
+// After the elimination (one lane per hypothesis, sA in LDS) the serial part of a
+// hypothesis is the root search (nine derivative levels, each a safeguarded Newton per
+// monotone piece) and the refinement of up to ten candidates.  Both are spread over a
+// group of SG = 16 consecutive lanes: lane g of the group owns the g-th monotone piece of a
+// level, then the g-th root.  The outcome equals the one-lane routines' (same operations
+// per piece, the same ordered bookkeeping).
+constexpr int SG = 16;
+constexpr int SOLVE_THREADS = ST * SG;
+
+struct SolveShared {
+    double cf[ST][11];
+    double bm[ST][3][13];
+    double EE[ST][4][9];
+    double rt[ST][2][12];       // the two alternating root lists
+    double cand[ST][SG][4];     // per piece: end point that is an exact zero, bracketed root,
+    uint8_t ctype[ST][SG][4];   // touching extremum, final end point (0 = none)
+    int32_t ok[ST];
+};
+
+__device__ __forceinline__ void group_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t group_ballot(bool p, int lane) {
+    return (uint32_t)(__ballot(p) >> (lane & 48)) & 0xFFFFu;
+}
+
+// One derivative level (degree DEG) for a group: sP holds the np roots of the next
+// derivative, the roots of this one go to sC (ascending); returns their number.
+template <int DEG>
+__device__ __forceinline__ int roots_level_group(const double* c, const double* sP, int np, double* sC, double* scand,
+                                                 uint8_t* stype, int g, int lane) {
+    constexpr int J = 10 - DEG;
+    double d[DEG + 1], dd[DEG];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const double* p = m + ((size_t)b * n_max + idx[i]) * 4;
-            x1[i * 2] = p[0]; x1[i * 2 + 1] = p[1];
-            x2[i * 2] = p[2]; x2[i * 2 + 1] = p[3];
+    for (int i = 0; i <= DEG; ++i) d[i] = c[i + J] * falling(i + J, J);
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
+    double R = 0;
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i] / d[DEG]));
+    R += 1.0;
+    const bool act = g <= np;
+    const double a = (act && g > 0) ? fmin(fmax(sP[g - 1], -R), R) : -R;
+    const double b = (act && g < np) ? fmin(fmax(sP[g], -R), R) : R;
+    const double fa = horner<DEG>(d, a), fb = horner<DEG>(d, b);
+    const bool inc = act && b > a;
+    const bool cA = inc && fa == 0.0;
+    const bool cX = inc && fa != 0.0 && ((fa < 0) != (fb < 0)) && fb != 0.0;
+    double x = 0;
+    if (cX) {
+        double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
+        x = 0.5 * (a + b);
+        double dxold = fabs(b - a), dx = dxold;
+        double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
+        for (int it = 0; it < 100; ++it) {
+            if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+                dxold = dx;
+                dx = 0.5 * (xh - xl);
+                x = xl + dx;
+            } else {
+                dxold = dx;
+                dx = f / df;
+                x -= dx;
+            }
+            if (fabs(dx) <= 4.0 * DBL_EPSILON * fmax(1.0, fabs(x))) break;
+            f = horner<DEG>(d, x);
+            df = horner<DEG - 1>(dd, x);
+            if (f == 0.0) break;
+            if (f < 0.0) xl = x; else xh = x;
         }
-        nm = five_point_dev(x1, x2, models + ((size_t)b * hr + h) * kMaxModels * 9, sA + threadIdx.x);
     }
-    if (h < hr) nmodels[(size_t)b * hr + h] = nm;
+    bool cT = false;
+    if (DEG == 10 && act && g < np && fb != 0.0) {
+        // a local extremum that touches zero to rounding level is a double root: keep it
+        double ab = fabs(b), mag = fabs(d[DEG]);
+#pragma unroll
+        for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
+        cT = fabs(fb) <= 1e-6 * mag;
+    }
+    const bool cF = act && g == np && fb == 0.0;
+    const uint32_t mX = group_ballot(cX, lane);
+    const uint32_t mOther = group_ballot(cA || cT || cF, lane);
+    int nc;
+    if (DEG < 10 && mOther == 0) {
+        // only bracketed roots, none of them subject to merging: ordered compaction
+        if (cX) sC[__popc(mX & ((1u << g) - 1u))] = x;
+        nc = __popc(mX);
+    } else {
+        scand[g * 4 + 0] = a; stype[g * 4 + 0] = cA ? 1 : 0;
+        scand[g * 4 + 1] = x; stype[g * 4 + 1] = cX ? 2 : 0;
+        scand[g * 4 + 2] = b; stype[g * 4 + 2] = cT ? 3 : 0;
+        scand[g * 4 + 3] = b; stype[g * 4 + 3] = cF ? 4 : 0;
+        group_sync();
+        // the ordered bookkeeping of the one-lane routine, replayed by every lane
+        nc = 0;
+        double last = 0;
+        for (int k = 0; k <= np; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ty = stype[k * 4 + t];
+                if (ty == 0) continue;
+                const double v = scand[k * 4 + t];
+                const bool near = nc > 0 && fabs(v - last) <= 1e-7 * fmax(1.0, fabs(v));
+                bool push;
+                if (ty == 1 || ty == 4) push = nc == 0 || last != v;
+                else if (ty == 2) push = !(DEG == 10 && near);
+                else push = !near;
+                if (push && nc < 10) {
+                    if (g == 0) sC[nc] = v;
+                    last = v;
+                    ++nc;
+                }
+            }
+        }
+    }
+    group_sync();
+    return nc;
+}
+
+// Workgroup of SOLVE_THREADS lanes, ST hypotheses.  x1/x2 are read by the first ST lanes
+// (lane h = hypothesis h, active[h] says whether it has a sample); Es/nm_out of hypothesis h
+// are written by its group.
+__device__ __forceinline__ void solve_hypotheses(bool active, const double* x1, const double* x2, double* sA,
+                                                 SolveShared& sh, double* __restrict__ Es_group,
+                                                 int32_t* __restrict__ nm_group) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < ST) {
+        bool ok = false;
+        if (active) {
+            double EE[4][9], bm[3][13], cf[11];
+            ok = five_point_front(x1, x2, sA + tid, EE, bm, cf);
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < 11; ++i) sh.cf[tid][i] = cf[i];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) sh.bm[tid][r][k] = bm[r][k];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) sh.EE[tid][t][k] = EE[t][k];
+            }
+        }
+        sh.ok[tid] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int h = tid / SG, g = tid % SG;
+    int count = 0;
+    if (sh.ok[h]) {   // uniform inside a group
+        double cf[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) cf[i] = sh.cf[h][i];
+        double cmax = 0;
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
+        double* A = sh.rt[h][0];
+        double* B = sh.rt[h][1];
+        double* scand = &sh.cand[h][0][0];
+        uint8_t* stype = &sh.ctype[h][0][0];
+        int nr;
+        if (fabs(cf[10]) > 1e-14 * cmax) {
+            if (g == 0) A[0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
+            group_sync();
+            nr = roots_level_group<2>(cf, A, 1, B, scand, stype, g, lane);
+            nr = roots_level_group<3>(cf, B, nr, A, scand, stype, g, lane);
+            nr = roots_level_group<4>(cf, A, nr, B, scand, stype, g, lane);
+            nr = roots_level_group<5>(cf, B, nr, A, scand, stype, g, lane);
+            nr = roots_level_group<6>(cf, A, nr, B, scand, stype, g, lane);
+            nr = roots_level_group<7>(cf, B, nr, A, scand, stype, g, lane);
+            nr = roots_level_group<8>(cf, A, nr, B, scand, stype, g, lane);
+            nr = roots_level_group<9>(cf, B, nr, A, scand, stype, g, lane);
+            nr = roots_level_group<10>(cf, A, nr, B, scand, stype, g, lane);
+        } else {   // degree-deficient polynomial (rare): generic one-lane path
+            if (g == 0) {
+                double roots[10];
+                int n = real_roots(cf, roots);
+                for (int k = 0; k < n; ++k) B[k] = roots[k];
+                B[10] = (double)n;
+            }
+            group_sync();
+            nr = (int)B[10];
+        }
+        // ---- candidate g: start values, refinement, acceptance
+        bool acc = false;
+        double Ev[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ev[k] = 0;
+        if (g < nr) {
+            double z1 = B[g], sx, sy;
+            double EE[4][9], bm[3][13];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) EE[t][k] = sh.EE[h][t][k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 13; ++k) bm[r][k] = sh.bm[h][r][k];
+            if (model_start(bm, z1, &sx, &sy)) {
+                double res = polish_model_dev(EE, sx, sy, z1, Ev);
+                acc = res <= 1e-9;   // settled on a solution
+            }
+        }
+        // two starts that settled on the same solution count once: a candidate falls if an
+        // accepted earlier one is within 1e-7 (either sign); decided in root order
+        for (int m = 0; m + 1 < nr; ++m) {
+            const bool acc_m = __shfl((int)acc, m, SG) != 0;   // final: depends on candidates < m only
+            double dp = 0, dm = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                double em = __shfl(Ev[k], m, SG);
+                dp = fmax(dp, fabs(em - Ev[k]));
+                dm = fmax(dm, fabs(em + Ev[k]));
+            }
+            if (acc_m && g > m && fmin(dp, dm) < 1e-7) acc = false;
+        }
+        const uint32_t macc = group_ballot(acc, lane);
+        if (acc) {
+            double* o = Es_group + __popc(macc & ((1u << g) - 1u)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = Ev[k];
+        }
+        count = __popc(macc);
+    }
+    if (g == 0 && nm_group) *nm_group = count;
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const RState* __restrict__ st, const double* __restrict__ m,
+                                                              int n_max, const int32_t* __restrict__ samples,
+                                                              int samples_stride, int h0, int hr,
+                                                              double* __restrict__ models, int32_t* __restrict__ nmodels) {
+    __shared__ double sA[200 * ST];
+    __shared__ SolveShared sh;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const RState& s = st[b];
+    if (s.done) return;   // uniform: nothing of this round is read any more
+    double x1[10], x2[10];
+    bool active = false;
+    if (tid < ST) {
+        const int h = blockIdx.x * ST + tid;
+        active = h < hr && (h0 + h) < s.niters;
+        if (active) {
+            const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double* p = m + ((size_t)b * n_max + idx[i]) * 4;
+                x1[i * 2] = p[0]; x1[i * 2 + 1] = p[1];
+                x2[i * 2] = p[2]; x2[i * 2 + 1] = p[3];
+            }
+        }
+    }
+    const int hg = blockIdx.x * ST + tid / SG;   // this group's hypothesis
+    const bool in_round = hg < hr;
+    solve_hypotheses(active, x1, x2, sA, sh, models + ((size_t)b * hr + (in_round ? hg : 0)) * kMaxModels * 9,
+                     in_round ? nmodels + (size_t)b * hr + hg : nullptr);
 }
 
 // Sampson error of EMEstimatorCallback::computeError, cast to float.
@@ -760,6 +1015,7 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
                                                     int32_t* __restrict__ counts) {
     __shared__ double sE[4][kMaxModels * 9];
     int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (st[b].done) return;   // workgroup-uniform: the solve kernel wrote nothing for this pair
     int h = blockIdx.x * 4 + wave;
     int nm = h < hr ? nmodels[(size_t)b * hr + h] : 0;   // wave-uniform
     const double* Eg = models + ((size_t)b * hr + h) * kMaxModels * 9;
@@ -1064,19 +1320,28 @@ __global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ 
 }
 
 // Five-point solver alone on caller-supplied minimal sets (normalised coordinates).
-__global__ __launch_bounds__(ST) void five_point_debug_kernel(const double* __restrict__ x1,
-                                                              const double* __restrict__ x2, int count,
-                                                              double* __restrict__ models,
-                                                              int32_t* __restrict__ nmodels) {
+__global__ __launch_bounds__(SOLVE_THREADS) void five_point_debug_kernel(const double* __restrict__ x1,
+                                                                         const double* __restrict__ x2, int count,
+                                                                         double* __restrict__ models,
+                                                                         int32_t* __restrict__ nmodels) {
     __shared__ double sA[200 * ST];
-    int h = blockIdx.x * ST + threadIdx.x;
-    if (h >= count) return;
+    __shared__ SolveShared sh;
+    const int tid = threadIdx.x;
     double a[10], b[10];
-    for (int i = 0; i < 10; ++i) {
-        a[i] = x1[h * 10 + i];
-        b[i] = x2[h * 10 + i];
+    bool active = false;
+    if (tid < ST) {
+        const int h = blockIdx.x * ST + tid;
+        active = h < count;
+        if (active)
+            for (int i = 0; i < 10; ++i) {
+                a[i] = x1[h * 10 + i];
+                b[i] = x2[h * 10 + i];
+            }
     }
-    nmodels[h] = five_point_dev(a, b, models + (size_t)h * kMaxModels * 9, sA + threadIdx.x);
+    const int hg = blockIdx.x * ST + tid / SG;
+    const bool in_range = hg < count;
+    solve_hypotheses(active, a, b, sA, sh, models + (size_t)(in_range ? hg : 0) * kMaxModels * 9,
+                     in_range ? nmodels + hg : nullptr);
 }
 
 static int round_size(int round, int fixed) {
@@ -1131,8 +1396,8 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         if (hr <= 0) break;
         int next = std::min(round_size(round + 1, fixed_iters), total - (h0 + hr));
         if (next < 0) next = 0;
-        hipLaunchKernelGGL(solve_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5, h0,
-                           hr, models, nmodels);
+        hipLaunchKernelGGL(solve_kernel, dim3((hr + ST - 1) / ST, batch), dim3(SOLVE_THREADS), 0, s, st, m, nm, samples,
+                           HR * 5, h0, hr, models, nmodels);
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2,
                            counts);
         hipLaunchKernelGGL(update_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
@@ -1242,7 +1507,7 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     VO_HIP(c, hipMemcpyAsync(d_in, x1, in_b, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemcpyAsync(d_in + (size_t)count * 10, x2, in_b, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemsetAsync(c->r_models.p, 0, out_b, c->stream));
-    hipLaunchKernelGGL(five_point_debug_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
+    hipLaunchKernelGGL(five_point_debug_kernel, dim3((count + ST - 1) / ST), dim3(SOLVE_THREADS), 0, c->stream, d_in,
                        d_in + (size_t)count * 10, count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
