@@ -12,6 +12,7 @@
 // the serial loop would have picked.
 #include <cfloat>
 #include <cmath>
+#include <limits>
 
 #include "vo_internal.h"
 
@@ -36,6 +37,7 @@ struct RParams {
     double fx_mean;
     double threshold;          // already divided by (fx+fy)/2
     float t2;                  // (float)(threshold^2)
+    double t2_mid;             // midpoint between t2 and the next float above it
     double confidence;
     int fixed_iters;
 };
@@ -995,7 +997,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const RState* __re
 }
 
 // Sampson error of EMEstimatorCallback::computeError, cast to float.
-__device__ __forceinline__ float sampson_dev(const double* E, double x1, double y1, double x2, double y2) {
+// The inlier test (float)(err) <= t2 without the division in the common case: the
+// double err = num / den rounds to a float <= t2 exactly when it lies below the midpoint
+// t2_mid between t2 and the next float, so num against t2_mid * den decides unless the two are
+// within 1e-15 relative (then the quotient is formed and rounded as written).
+__device__ __forceinline__ bool sampson_inlier_dev(const double* E, double x1, double y1, double x2, double y2, float t2,
+                                                   double t2_mid) {
     double Ex0 = E[0] * x1 + E[1] * y1 + E[2];
     double Ex1 = E[3] * x1 + E[4] * y1 + E[5];
     double Ex2 = E[6] * x1 + E[7] * y1 + E[8];
@@ -1003,7 +1010,11 @@ __device__ __forceinline__ float sampson_dev(const double* E, double x1, double 
     double Et1 = E[1] * x2 + E[4] * y2 + E[7];
     double x2tEx1 = x2 * Ex0 + y2 * Ex1 + Ex2;
     double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
-    return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+    double num = x2tEx1 * x2tEx1, den = a + b + c + d;
+    double r = t2_mid * den;
+    if (num < r * (1.0 - 1e-15)) return true;
+    if (num > r * (1.0 + 1e-15)) return false;
+    return (float)(num / den) <= t2;
 }
 
 // One wavefront per hypothesis: every lane walks the points with stride 64,
@@ -1011,7 +1022,7 @@ __device__ __forceinline__ float sampson_dev(const double* E, double x1, double 
 // counts are summed across the wave.
 __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ st, const double* __restrict__ m,
                                                     int n_max, int hr, const double* __restrict__ models,
-                                                    const int32_t* __restrict__ nmodels, float t2,
+                                                    const int32_t* __restrict__ nmodels, float t2, double t2_mid,
                                                     int32_t* __restrict__ counts) {
     __shared__ double sE[4][kMaxModels * 9];
     int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1031,7 +1042,7 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
         const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)i * 4);
 #pragma unroll
         for (int k = 0; k < kMaxModels; ++k)
-            if (k < nm) cnt[k] += sampson_dev(&sE[wave][k * 9], p.x, p.y, p.z, p.w) <= t2;
+            if (k < nm) cnt[k] += sampson_inlier_dev(&sE[wave][k * 9], p.x, p.y, p.z, p.w, t2, t2_mid);
     }
 #pragma unroll
     for (int k = 0; k < kMaxModels; ++k) {
@@ -1043,36 +1054,50 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     }
 }
 
-// Sequential RANSAC bookkeeping over one round, then the next round's samples.
-__global__ void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
-                              const double* __restrict__ models, const int32_t* __restrict__ nmodels,
-                              const int32_t* __restrict__ counts, int32_t* __restrict__ samples, int samples_stride,
-                              int next_round, int32_t* __restrict__ samples_log, int log_cap) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    RState s = stv[b];
-    if (s.done) return;
+// Sequential RANSAC bookkeeping over one round, then the next round's samples.  One
+// wavefront per pair: the round's model counts are staged in LDS with coalesced loads, lane 0
+// then replays the serial loop on them (a dependent global load per step otherwise).
+constexpr int UPD_MAX_HR = 512;
+__global__ __launch_bounds__(64) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
+                                                    const double* __restrict__ models, const int32_t* __restrict__ nmodels,
+                                                    const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
+                                                    int samples_stride, int next_round, int32_t* __restrict__ samples_log,
+                                                    int log_cap) {
+    __shared__ int32_t s_nm[UPD_MAX_HR];
+    __shared__ int32_t s_cnt[UPD_MAX_HR * kMaxModels];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (stv[b].done) return;   // workgroup-uniform
+    const int live = min(hr, max(stv[b].niters - h0, 0));   // hypotheses the serial loop can reach
+    for (int h = lane; h < live; h += 64) s_nm[h] = nmodels[(size_t)b * hr + h];
+    for (int i = lane; i < live * kMaxModels; i += 64) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
     if (samples_log) {
         const int32_t* src = samples + (size_t)b * samples_stride;
-        for (int h = 0; h < hr && h0 + h < s.niters && h0 + h < log_cap; ++h)
-            for (int i = 0; i < 5; ++i) samples_log[((size_t)b * log_cap + h0 + h) * 5 + i] = src[h * 5 + i];
+        const int lim = min(live, log_cap - h0);
+        for (int i = lane; i < lim * 5; i += 64) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
     }
-    int h = 0;
+    __syncthreads();
+    if (lane != 0) return;
+    RState s = stv[b];
+    int h = 0, best_h = -1, best_k = 0;
     for (; h < hr; ++h) {
         if (h0 + h >= s.niters) break;
-        int nm = nmodels[(size_t)b * hr + h];
+        int nm = s_nm[h];
         if (s.exact5 && nm != 1) nm = 0;
         for (int k = 0; k < nm; ++k) {
-            int good = counts[((size_t)b * hr + h) * kMaxModels + k];
+            int good = s_cnt[h * kMaxModels + k];
             if (good > max(s.max_good, 4)) {
                 s.max_good = good;
-                const double* E = models + (((size_t)b * hr + h) * kMaxModels + k) * 9;
-                for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
+                best_h = h;
+                best_k = k;
                 if (P.fixed_iters <= 0 && !s.exact5)
                     s.niters = update_num_iters(P.confidence, (double)(s.n - good) / s.n, s.niters);
             }
         }
         s.iters_run = h0 + h + 1;
+    }
+    if (best_h >= 0) {
+        const double* E = models + (((size_t)b * hr + best_h) * kMaxModels + best_k) * 9;
+        for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
     }
     if (h < hr || h0 + hr >= s.niters) {
         s.done = 1;
@@ -1138,6 +1163,62 @@ __device__ void smallest_eigvec4(double S[4][4], double* v) {
     for (int k = 0; k < 4; ++k) v[k] = best == 0 ? V[k][0] : best == 1 ? V[k][1] : best == 2 ? V[k][2] : V[k][3];
 }
 
+// The same eigenvector without the Jacobi sweeps when the smallest eigenvalue is well
+// separated (every triangulation with usable parallax): the adjugate of S has the
+// eigenvectors of S with eigenvalues prod_{j != i} lambda_j, so the wanted one is its
+// dominant eigenvector and a few products adj(S) v converge at the rate lambda_1/lambda_2.
+// Returns false (v untouched) when eight products do not settle to 4e-16; the caller then
+// takes the Jacobi route.
+__device__ __forceinline__ bool smallest_eigvec4_adj(const double S[4][4], double* v) {
+    double C[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) {
+            // cofactor (i, j): rows without i, columns without j
+            const int r0 = i == 0 ? 1 : 0, r1 = i <= 1 ? 2 : 1, r2 = i <= 2 ? 3 : 2;
+            const int c0 = j == 0 ? 1 : 0, c1 = j <= 1 ? 2 : 1, c2 = j <= 2 ? 3 : 2;
+            double d = S[r0][c0] * (S[r1][c1] * S[r2][c2] - S[r1][c2] * S[r2][c1]) -
+                       S[r0][c1] * (S[r1][c0] * S[r2][c2] - S[r1][c2] * S[r2][c0]) +
+                       S[r0][c2] * (S[r1][c0] * S[r2][c1] - S[r1][c1] * S[r2][c0]);
+            C[i][j] = C[j][i] = ((i + j) & 1) ? -d : d;
+        }
+    // start from the column with the largest diagonal entry
+    int best = 0;
+    double bv = C[0][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (C[i][i] > bv) { bv = C[i][i]; best = i; }
+    if (!(bv > 0)) return false;
+    double x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = best == 0 ? C[k][0] : best == 1 ? C[k][1] : best == 2 ? C[k][2] : C[k][3];
+    double nrm = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] *= nrm;
+    for (int it = 0; it < 8; ++it) {
+        double y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = C[k][0] * x[0] + C[k][1] * x[1] + C[k][2] * x[2] + C[k][3] * x[3];
+        double n2 = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+        if (!(n2 > 0)) return false;
+        nrm = 1.0 / sqrt(n2);
+        double dmax = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y[k] *= nrm;
+            dmax = fmax(dmax, fabs(y[k] - x[k]));
+            x[k] = y[k];
+        }
+        if (dmax <= 4e-16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = x[k];
+            return true;
+        }
+    }
+    return false;
+}
+
 // decomposeEssentialMat: E = U diag(s,s,0) V^T -> R1 = U W V^T, R2 = U W^T V^T, t = u3.
 __device__ void decompose_essential_dev(const double* E, double* R1, double* R2, double* t) {
     // eigen-decomposition of E^T E (3x3) by Jacobi -> V
@@ -1151,24 +1232,30 @@ __device__ void decompose_essential_dev(const double* E, double* R1, double* R2,
         }
     for (int sweep = 0; sweep < 16; ++sweep) {
         double offd = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
-        if (offd == 0) break;
+        double diag = S[0][0] * S[0][0] + S[1][1] * S[1][1] + S[2][2] * S[2][2];
+        if (offd <= 1e-40 * diag) break;   // off-diagonal part below 1e-20 relative: converged in double
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 double apq = S[p][q];
                 if (apq == 0.0) continue;
                 double theta = (S[q][q] - S[p][p]) / (2.0 * apq);
                 double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     double skp = S[k][p], skq = S[k][q];
                     S[k][p] = c * skp - s * skq;
                     S[k][q] = s * skp + c * skq;
                 }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     double spk = S[p][k], sqk = S[q][k];
                     S[p][k] = c * spk - s * sqk;
                     S[q][k] = s * spk + c * sqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     double vkp = V[k][p], vkq = V[k][q];
                     V[k][p] = c * vkp - s * vkq;
@@ -1183,11 +1270,13 @@ __device__ void decompose_essential_dev(const double* E, double* R1, double* R2,
     if (e2 > e0) { double tt = e0; e0 = e2; e2 = tt; int ti = o0; o0 = o2; o2 = ti; }
     if (e2 > e1) { double tt = e1; e1 = e2; e2 = tt; int ti = o1; o1 = o2; o2 = ti; }
     double v1[3], v2[3], v3[3], u1[3], u2[3], u3[3];
+#pragma unroll
     for (int k = 0; k < 3; ++k) { v1[k] = V[k][o0]; v2[k] = V[k][o1]; }
     v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
     v3[1] = v1[2] * v2[0] - v1[0] * v2[2];
     v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
     double n1 = 0, n2 = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
         u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
@@ -1195,12 +1284,15 @@ __device__ void decompose_essential_dev(const double* E, double* R1, double* R2,
         n2 += u2[i] * u2[i];
     }
     n1 = 1.0 / sqrt(n1);
+#pragma unroll
     for (int i = 0; i < 3; ++i) u1[i] *= n1;
     // re-orthogonalise u2 against u1 (repeated singular value)
     double d12 = (u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2]);
     n2 = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) { u2[i] -= d12 * u1[i]; n2 += u2[i] * u2[i]; }
     n2 = 1.0 / sqrt(n2);
+#pragma unroll
     for (int i = 0; i < 3; ++i) u2[i] *= n2;
     u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
     u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
@@ -1208,7 +1300,9 @@ __device__ void decompose_essential_dev(const double* E, double* R1, double* R2,
     // U = [u1 u2 u3], V = [v1 v2 v3] both with det +1.
     // U W V^T  = u1 (-v2)^T... expand: W = [0 1 0; -1 0 0; 0 0 1]
     // (U W)   = [-u2, u1, u3];  (U W^T) = [u2, -u1, u3]
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             R1[i * 3 + j] = -u2[i] * v1[j] + u1[i] * v2[j] + u3[i] * v3[j];
             R2[i * 3 + j] = u2[i] * v1[j] - u1[i] * v2[j] + u3[i] * v3[j];
@@ -1216,17 +1310,19 @@ __device__ void decompose_essential_dev(const double* E, double* R1, double* R2,
     t[0] = u3[0]; t[1] = u3[1]; t[2] = u3[2];
 }
 
-// One workgroup per pair: inlier mask of the winning E, four-fold
-// triangulation/cheirality test, pose selection and validity rules.
-__global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ stv, const double* __restrict__ m,
-                                                     int n_max, RParams P, vo_pair_result* __restrict__ res,
-                                                     double* __restrict__ E_out, uint8_t* __restrict__ mask_e,
-                                                     uint8_t* __restrict__ mask_pose, int32_t* __restrict__ good_out) {
+// One workgroup of 1024 lanes per pair: inlier mask of the winning E, four-fold
+// triangulation/cheirality test (one quarter of the workgroup per candidate pose), pose
+// selection and validity rules.
+constexpr int FIN_T = 256;   // lanes per candidate pose
+__global__ __launch_bounds__(4 * FIN_T) void finish_kernel(const RState* __restrict__ stv, const double* __restrict__ m,
+                                                           int n_max, RParams P, vo_pair_result* __restrict__ res,
+                                                           double* __restrict__ E_out, uint8_t* __restrict__ mask_e,
+                                                           uint8_t* __restrict__ mask_pose, int32_t* __restrict__ good_out) {
     __shared__ double sR[2][9], sT[3], sE[9];
     __shared__ int cnt[4], sel;
-    int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid / FIN_T, j = tid % FIN_T;
     const RState& s = stv[b];
-    int n = s.n;
+    const int n = s.n;
     vo_pair_result* r = res ? res + b : nullptr;
     if (tid < 4) cnt[tid] = 0;
     if (tid < 9) sE[tid] = s.bestE[tid];
@@ -1243,57 +1339,63 @@ __global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ 
         }
     }
     if (s.max_good <= 0) {   // block-uniform
-        if (mask_e) for (int i = tid; i < n; i += 256) mask_e[(size_t)b * n_max + i] = 0;
-        if (mask_pose) for (int i = tid; i < n; i += 256) mask_pose[(size_t)b * n_max + i] = 0;
+        if (mask_e) for (int i = tid; i < n; i += 4 * FIN_T) mask_e[(size_t)b * n_max + i] = 0;
+        if (mask_pose) for (int i = tid; i < n; i += 4 * FIN_T) mask_pose[(size_t)b * n_max + i] = 0;
         return;
     }
     if (tid == 0) decompose_essential_dev(s.bestE, sR[0], sR[1], sT);
     __syncthreads();
     const double* pb = m + (size_t)b * n_max * 4;
-    int my[4] = {0, 0, 0, 0};
-    unsigned char* scratch_mask = mask_pose ? mask_pose + (size_t)b * n_max : nullptr;
-    for (int i = tid; i < n; i += 256) {
-        double x1 = pb[i * 4], y1 = pb[i * 4 + 1], x2 = pb[i * 4 + 2], y2 = pb[i * 4 + 3];
-        bool inl = s.exact5 ? true : (sampson_dev(sE, x1, y1, x2, y2) <= P.t2);
-        if (mask_e) mask_e[(size_t)b * n_max + i] = inl;
-        unsigned bits = 0;
-        for (int c = 0; c < 4; ++c) {
-            const double* R = sR[c & 1];
-            double sg = c < 2 ? 1.0 : -1.0;
-            double Pm[3][4];
-            for (int a = 0; a < 3; ++a) {
-                Pm[a][0] = R[a * 3]; Pm[a][1] = R[a * 3 + 1]; Pm[a][2] = R[a * 3 + 2];
-                Pm[a][3] = sg * sT[a];
-            }
-            // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for P0 = [I|0] and P
-            double A[4][4];
-            A[0][0] = -1; A[0][1] = 0; A[0][2] = x1; A[0][3] = 0;
-            A[1][0] = 0; A[1][1] = -1; A[1][2] = y1; A[1][3] = 0;
-            for (int k = 0; k < 4; ++k) {
-                A[2][k] = x2 * Pm[2][k] - Pm[0][k];
-                A[3][k] = y2 * Pm[2][k] - Pm[1][k];
-            }
-            double S[4][4];
-            for (int a = 0; a < 4; ++a)
-                for (int k = 0; k < 4; ++k)
-                    S[a][k] = A[0][a] * A[0][k] + A[1][a] * A[1][k] + A[2][a] * A[2][k] + A[3][a] * A[3][k];
-            double X[4];
-            smallest_eigvec4(S, X);
-            bool ok = X[2] * X[3] > 0;
-            double Xn0 = X[0] / X[3], Xn1 = X[1] / X[3], Xn2 = X[2] / X[3];
-            ok = ok && (Xn2 < 50.0);
-            double z2 = Pm[2][0] * Xn0 + Pm[2][1] * Xn1 + Pm[2][2] * Xn2 + Pm[2][3];
-            ok = ok && (z2 > 0) && (z2 < 50.0) && inl;
-            bits |= (unsigned)ok << c;
-            my[c] += ok;
+    auto load_pose = [&](int cand, double (*Pm)[4]) {   // [R | +-t]
+        const double* R = sR[cand & 1];
+        const double sg = cand < 2 ? 1.0 : -1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            Pm[a][0] = R[a * 3]; Pm[a][1] = R[a * 3 + 1]; Pm[a][2] = R[a * 3 + 2];
+            Pm[a][3] = sg * sT[a];
         }
-        if (scratch_mask) scratch_mask[i] = (unsigned char)bits;
+    };
+    // triangulates point i against [I|0] and Pm; true if it is an inlier of E in front of both
+    // cameras and nearer than 50 baselines
+    auto in_front = [&](int i, const double (*Pm)[4], bool* inl_out) -> bool {
+        double x1 = pb[i * 4], y1 = pb[i * 4 + 1], x2 = pb[i * 4 + 2], y2 = pb[i * 4 + 3];
+        bool inl = s.exact5 ? true : sampson_inlier_dev(sE, x1, y1, x2, y2, P.t2, P.t2_mid);
+        *inl_out = inl;
+        if (!inl) return false;   // only inliers of E take part in the cheirality vote
+        // DLT rows: x*P[2]-P[0], y*P[2]-P[1] for P0 = [I|0] and P
+        double A[4][4];
+        A[0][0] = -1; A[0][1] = 0; A[0][2] = x1; A[0][3] = 0;
+        A[1][0] = 0; A[1][1] = -1; A[1][2] = y1; A[1][3] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            A[2][q] = x2 * Pm[2][q] - Pm[0][q];
+            A[3][q] = y2 * Pm[2][q] - Pm[1][q];
+        }
+        double S[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                S[a][q] = A[0][a] * A[0][q] + A[1][a] * A[1][q] + A[2][a] * A[2][q] + A[3][a] * A[3][q];
+        double X[4];
+        if (!smallest_eigvec4_adj(S, X)) smallest_eigvec4(S, X);
+        bool ok = X[2] * X[3] > 0;
+        double Xn0 = X[0] / X[3], Xn1 = X[1] / X[3], Xn2 = X[2] / X[3];
+        ok = ok && (Xn2 < 50.0);
+        double z2 = Pm[2][0] * Xn0 + Pm[2][1] * Xn1 + Pm[2][2] * Xn2 + Pm[2][3];
+        return ok && (z2 > 0) && (z2 < 50.0) && inl;
+    };
+    double Pm[3][4];
+    load_pose(c, Pm);
+    int mine = 0;
+    for (int i = j; i < n; i += FIN_T) {
+        bool inl;
+        mine += in_front(i, Pm, &inl);
+        if (mask_e && c == 0) mask_e[(size_t)b * n_max + i] = inl;
     }
-    for (int c = 0; c < 4; ++c) {
-        int v = my[c];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) == 0) atomicAdd(&cnt[c], v);
-    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((tid & 63) == 0) atomicAdd(&cnt[c], mine);
     __syncthreads();
     if (tid == 0) {
         int g1 = cnt[0], g2 = cnt[1], g3 = cnt[2], g4 = cnt[3], sl;
@@ -1303,19 +1405,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const RState* __restrict__ 
         else sl = 3;
         sel = sl;
         int good = cnt[sl];
-        if (r) {
-            if (good >= 10) {
-                r->valid = 1;
-                r->inliers = good;
-                for (int k = 0; k < 9; ++k) r->R[k] = sR[sl & 1][k];
-                for (int k = 0; k < 3; ++k) r->t[k] = (sl < 2 ? 1.0 : -1.0) * sT[k];
-            }
+        if (r && good >= 10) {
+            r->valid = 1;
+            r->inliers = good;
+            for (int k = 0; k < 9; ++k) r->R[k] = sR[sl & 1][k];
+            for (int k = 0; k < 3; ++k) r->t[k] = (sl < 2 ? 1.0 : -1.0) * sT[k];
         }
     }
+    if (!mask_pose) return;
     __syncthreads();
-    if (scratch_mask) {
-        int sl = sel;
-        for (int i = tid; i < n; i += 256) scratch_mask[i] = (scratch_mask[i] >> sl) & 1;
+    // the winning pose's per-point outcome, recomputed by the whole workgroup
+    load_pose(sel, Pm);
+    for (int i = tid; i < n; i += 4 * FIN_T) {
+        bool inl;
+        mask_pose[(size_t)b * n_max + i] = in_front(i, Pm, &inl);
     }
 }
 
@@ -1364,6 +1467,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     P.fx_mean = (K[0] + K[1]) / 2;
     P.threshold = threshold / P.fx_mean;
     P.t2 = (float)(P.threshold * P.threshold);
+    P.t2_mid = 0.5 * ((double)P.t2 + (double)std::nextafter(P.t2, std::numeric_limits<float>::infinity()));
     P.confidence = confidence;
     P.fixed_iters = fixed_iters;
     const int HR = 512;   // largest round
@@ -1398,13 +1502,13 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         if (next < 0) next = 0;
         hipLaunchKernelGGL(solve_kernel, dim3((hr + ST - 1) / ST, batch), dim3(SOLVE_THREADS), 0, s, st, m, nm, samples,
                            HR * 5, h0, hr, models, nmodels);
-        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2,
+        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
-        hipLaunchKernelGGL(update_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
+        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
                            counts, samples, HR * 5, next, d_samples, samples_cap);
         h0 += hr;
     }
-    hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(256), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
+    hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(4 * FIN_T), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
                        d_good);
     t_end(c, VO_T_RANSAC);
     VO_HIP(c, hipGetLastError());
