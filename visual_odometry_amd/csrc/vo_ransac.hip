@@ -693,7 +693,7 @@ __host__ __device__ __forceinline__ bool model_start(const double (*bm)[13], dou
 
 // x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm essential matrices
 // (row-major) to Es.  One lane does everything (host harness; the device path splits the
-// root search and the refinement over sixteen lanes, see solve_hypotheses).
+// root search and the refinement over sixteen lanes, see solve_back).
 __host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
     double EE[4][9], bm[3][13], cf[11];
     if (!five_point_front(x1, x2, sA, EE, bm, cf)) return 0;
@@ -745,15 +745,13 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
 // per piece, the same ordered bookkeeping).
 constexpr int SG = 16;
 constexpr int SOLVE_THREADS = ST * SG;
-
-struct SolveShared {
-    double cf[ST][11];
-    double bm[ST][3][13];
-    double EE[ST][4][9];
+// What the front end (one lane per hypothesis) hands to the root search: determinant
+// polynomial, the three reduced constraint rows, the null-space basis; [0] = 1 if usable.
+constexpr int HYP_REC = 88;   // doubles: flag, cf[11], bm[3][13], EE[4][9], one pad
+struct RootScratch {
     double rt[ST][2][12];       // the two alternating root lists
     double cand[ST][SG][4];     // per piece: end point that is an exact zero, bracketed root,
     uint8_t ctype[ST][SG][4];   // touching extremum, final end point (0 = none)
-    int32_t ok[ST];
 };
 
 __device__ __forceinline__ void group_sync() {
@@ -775,10 +773,11 @@ __device__ __forceinline__ int roots_level_group(const double* c, const double* 
     for (int i = 0; i <= DEG; ++i) d[i] = c[i + J] * falling(i + J, J);
 #pragma unroll
     for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
+    // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
     double R = 0;
 #pragma unroll
-    for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i] / d[DEG]));
-    R += 1.0;
+    for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i]));
+    R = R / fabs(d[DEG]) * (1.0 + 1e-12) + 1.0;
     const bool act = g <= np;
     const double a = (act && g > 0) ? fmin(fmax(sP[g - 1], -R), R) : -R;
     const double b = (act && g < np) ? fmin(fmax(sP[g], -R), R) : R;
@@ -857,47 +856,48 @@ __device__ __forceinline__ int roots_level_group(const double* c, const double* 
     return nc;
 }
 
-// Workgroup of SOLVE_THREADS lanes, ST hypotheses.  x1/x2 are read by the first ST lanes
-// (lane h = hypothesis h, active[h] says whether it has a sample); Es/nm_out of hypothesis h
-// are written by its group.
-__device__ __forceinline__ void solve_hypotheses(bool active, const double* x1, const double* x2, double* sA,
-                                                 SolveShared& sh, double* __restrict__ Es_group,
-                                                 int32_t* __restrict__ nm_group) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < ST) {
-        bool ok = false;
-        if (active) {
-            double EE[4][9], bm[3][13], cf[11];
-            ok = five_point_front(x1, x2, sA + tid, EE, bm, cf);
-            if (ok) {
+// Front end of one hypothesis per lane (ST lanes per workgroup, the elimination matrix in
+// LDS): writes the hypothesis record.
+__device__ __forceinline__ void solve_front(bool active, const double* x1, const double* x2, double* sA,
+                                            double* __restrict__ rec) {
+    bool ok = false;
+    if (active) {
+        double EE[4][9], bm[3][13], cf[11];
+        ok = five_point_front(x1, x2, sA + threadIdx.x, EE, bm, cf);
+        if (ok) {
 #pragma unroll
-                for (int i = 0; i < 11; ++i) sh.cf[tid][i] = cf[i];
+            for (int i = 0; i < 11; ++i) rec[1 + i] = cf[i];
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int k = 0; k < 13; ++k) sh.bm[tid][r][k] = bm[r][k];
+                for (int k = 0; k < 13; ++k) rec[12 + r * 13 + k] = bm[r][k];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) sh.EE[tid][t][k] = EE[t][k];
-            }
+                for (int k = 0; k < 9; ++k) rec[51 + t * 9 + k] = EE[t][k];
         }
-        sh.ok[tid] = ok ? 1 : 0;
     }
-    __syncthreads();
+    rec[0] = ok ? 1.0 : 0.0;
+}
+
+// Root search and refinement of one hypothesis by a group of SG lanes (h = group index in the
+// workgroup): reads the record, writes the models and their number.
+__device__ __forceinline__ void solve_back(const double* __restrict__ rec, RootScratch& rs, double* __restrict__ Es_group,
+                                           int32_t* __restrict__ nm_group) {
+    const int tid = threadIdx.x, lane = tid & 63;
     const int h = tid / SG, g = tid % SG;
     int count = 0;
-    if (sh.ok[h]) {   // uniform inside a group
+    if (rec && rec[0] != 0.0) {   // uniform inside a group
         double cf[11];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) cf[i] = sh.cf[h][i];
+        for (int i = 0; i < 11; ++i) cf[i] = rec[1 + i];
         double cmax = 0;
 #pragma unroll
         for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
-        double* A = sh.rt[h][0];
-        double* B = sh.rt[h][1];
-        double* scand = &sh.cand[h][0][0];
-        uint8_t* stype = &sh.ctype[h][0][0];
+        double* A = rs.rt[h][0];
+        double* B = rs.rt[h][1];
+        double* scand = &rs.cand[h][0][0];
+        uint8_t* stype = &rs.ctype[h][0][0];
         int nr;
         if (fabs(cf[10]) > 1e-14 * cmax) {
             if (g == 0) A[0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
@@ -930,13 +930,13 @@ __device__ __forceinline__ void solve_hypotheses(bool active, const double* x1, 
             double z1 = B[g], sx, sy;
             double EE[4][9], bm[3][13];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) EE[t][k] = sh.EE[h][t][k];
-#pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int k = 0; k < 13; ++k) bm[r][k] = sh.bm[h][r][k];
+                for (int k = 0; k < 13; ++k) bm[r][k] = rec[12 + r * 13 + k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
             if (model_start(bm, z1, &sx, &sy)) {
                 double res = polish_model_dev(EE, sx, sy, z1, Ev);
                 acc = res <= 1e-9;   // settled on a solution
@@ -966,37 +966,41 @@ __device__ __forceinline__ void solve_hypotheses(bool active, const double* x1, 
     if (g == 0 && nm_group) *nm_group = count;
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const RState* __restrict__ st, const double* __restrict__ m,
-                                                              int n_max, const int32_t* __restrict__ samples,
-                                                              int samples_stride, int h0, int hr,
-                                                              double* __restrict__ models, int32_t* __restrict__ nmodels) {
+__global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restrict__ st, const double* __restrict__ m,
+                                                         int n_max, const int32_t* __restrict__ samples,
+                                                         int samples_stride, int h0, int hr, double* __restrict__ recs) {
     __shared__ double sA[200 * ST];
-    __shared__ SolveShared sh;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, h = blockIdx.x * ST + threadIdx.x;
     const RState& s = st[b];
-    if (s.done) return;   // uniform: nothing of this round is read any more
+    if (s.done || h >= hr) return;   // a finished pair reads nothing of this round any more
     double x1[10], x2[10];
-    bool active = false;
-    if (tid < ST) {
-        const int h = blockIdx.x * ST + tid;
-        active = h < hr && (h0 + h) < s.niters;
-        if (active) {
-            const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
+    const bool active = (h0 + h) < s.niters;
+    if (active) {
+        const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const double* p = m + ((size_t)b * n_max + idx[i]) * 4;
-                x1[i * 2] = p[0]; x1[i * 2 + 1] = p[1];
-                x2[i * 2] = p[2]; x2[i * 2 + 1] = p[3];
-            }
+        for (int i = 0; i < 5; ++i) {
+            const double* p = m + ((size_t)b * n_max + idx[i]) * 4;
+            x1[i * 2] = p[0]; x1[i * 2 + 1] = p[1];
+            x2[i * 2] = p[2]; x2[i * 2 + 1] = p[3];
         }
     }
-    const int hg = blockIdx.x * ST + tid / SG;   // this group's hypothesis
-    const bool in_round = hg < hr;
-    solve_hypotheses(active, x1, x2, sA, sh, models + ((size_t)b * hr + (in_round ? hg : 0)) * kMaxModels * 9,
-                     in_round ? nmodels + (size_t)b * hr + hg : nullptr);
+    solve_front(active, x1, x2, sA, recs + ((size_t)b * hr + h) * HYP_REC);
 }
 
-// Sampson error of EMEstimatorCallback::computeError, cast to float.
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
+                                                                   const double* __restrict__ recs,
+                                                                   double* __restrict__ models,
+                                                                   int32_t* __restrict__ nmodels) {
+    __shared__ RootScratch rs;
+    const int b = blockIdx.y;
+    if (st[b].done) return;
+    const int hg = blockIdx.x * ST + threadIdx.x / SG;   // this group's hypothesis
+    const bool in_round = hg < hr;
+    const size_t slot = (size_t)b * hr + (in_round ? hg : 0);
+    solve_back(in_round ? recs + slot * HYP_REC : nullptr, rs, models + slot * kMaxModels * 9,
+               in_round ? nmodels + slot : nullptr);
+}
+
 // The inlier test (float)(err) <= t2 without the division in the common case: the
 // double err = num / den rounds to a float <= t2 exactly when it lies below the midpoint
 // t2_mid between t2 and the next float, so num against t2_mid * den decides unless the two are
@@ -1423,28 +1427,29 @@ __global__ __launch_bounds__(4 * FIN_T) void finish_kernel(const RState* __restr
 }
 
 // Five-point solver alone on caller-supplied minimal sets (normalised coordinates).
-__global__ __launch_bounds__(SOLVE_THREADS) void five_point_debug_kernel(const double* __restrict__ x1,
-                                                                         const double* __restrict__ x2, int count,
-                                                                         double* __restrict__ models,
-                                                                         int32_t* __restrict__ nmodels) {
+__global__ __launch_bounds__(ST) void five_point_debug_front_kernel(const double* __restrict__ x1,
+                                                                    const double* __restrict__ x2, int count,
+                                                                    double* __restrict__ recs) {
     __shared__ double sA[200 * ST];
-    __shared__ SolveShared sh;
-    const int tid = threadIdx.x;
+    const int h = blockIdx.x * ST + threadIdx.x;
+    if (h >= count) return;
     double a[10], b[10];
-    bool active = false;
-    if (tid < ST) {
-        const int h = blockIdx.x * ST + tid;
-        active = h < count;
-        if (active)
-            for (int i = 0; i < 10; ++i) {
-                a[i] = x1[h * 10 + i];
-                b[i] = x2[h * 10 + i];
-            }
+    for (int i = 0; i < 10; ++i) {
+        a[i] = x1[h * 10 + i];
+        b[i] = x2[h * 10 + i];
     }
-    const int hg = blockIdx.x * ST + tid / SG;
+    solve_front(true, a, b, sA, recs + (size_t)h * HYP_REC);
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void five_point_debug_back_kernel(int count, const double* __restrict__ recs,
+                                                                              double* __restrict__ models,
+                                                                              int32_t* __restrict__ nmodels) {
+    __shared__ RootScratch rs;
+    const int hg = blockIdx.x * ST + threadIdx.x / SG;
     const bool in_range = hg < count;
-    solve_hypotheses(active, a, b, sA, sh, models + (size_t)(in_range ? hg : 0) * kMaxModels * 9,
-                     in_range ? nmodels + hg : nullptr);
+    const size_t slot = in_range ? hg : 0;
+    solve_back(in_range ? recs + slot * HYP_REC : nullptr, rs, models + slot * kMaxModels * 9,
+               in_range ? nmodels + slot : nullptr);
 }
 
 static int round_size(int round, int fixed) {
@@ -1478,12 +1483,14 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if ((rc = ensure(c, c->r_samples, (size_t)batch * HR * 5 * 4))) return rc;
     if ((rc = ensure(c, c->r_models, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_nmodels, (size_t)batch * HR * 4))) return rc;
+    if ((rc = ensure(c, c->r_best, (size_t)batch * HR * HYP_REC * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
     RState* st = (RState*)c->r_state.p;
     double* m = (double*)c->r_pts.p;
     int32_t* samples = (int32_t*)c->r_samples.p;
     double* models = (double*)c->r_models.p;
     int32_t* nmodels = (int32_t*)c->r_nmodels.p;
+    double* recs = (double*)c->r_best.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
 
     t_begin(c, VO_T_RANSAC);
@@ -1500,8 +1507,10 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         if (hr <= 0) break;
         int next = std::min(round_size(round + 1, fixed_iters), total - (h0 + hr));
         if (next < 0) next = 0;
-        hipLaunchKernelGGL(solve_kernel, dim3((hr + ST - 1) / ST, batch), dim3(SOLVE_THREADS), 0, s, st, m, nm, samples,
-                           HR * 5, h0, hr, models, nmodels);
+        hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
+                           h0, hr, recs);
+        hipLaunchKernelGGL(solve_back_kernel, dim3((hr + ST - 1) / ST, batch), dim3(SOLVE_THREADS), 0, s, st, hr, recs,
+                           models, nmodels);
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
@@ -1611,8 +1620,11 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     VO_HIP(c, hipMemcpyAsync(d_in, x1, in_b, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemcpyAsync(d_in + (size_t)count * 10, x2, in_b, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemsetAsync(c->r_models.p, 0, out_b, c->stream));
-    hipLaunchKernelGGL(five_point_debug_kernel, dim3((count + ST - 1) / ST), dim3(SOLVE_THREADS), 0, c->stream, d_in,
-                       d_in + (size_t)count * 10, count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
+    if ((rc = ensure(c, c->r_best, (size_t)count * HYP_REC * 8))) return rc;
+    hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
+                       d_in + (size_t)count * 10, count, (double*)c->r_best.p);
+    hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + ST - 1) / ST), dim3(SOLVE_THREADS), 0, c->stream, count,
+                       (const double*)c->r_best.p, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(n_models, c->r_nmodels.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
