@@ -63,12 +63,15 @@ const char* vo_last_error(const vo_ctx* ctx);
 /* hipStream_t the context enqueues on (as void*). */
 void* vo_ctx_stream(vo_ctx* ctx);
 int vo_sync(vo_ctx* ctx);
-/* Kernel timing with HIP events recorded on the context's stream.  While
- * enabled, every launch of an instrumented kernel group is bracketed by a
- * fresh event pair (nothing waits on them, so the pipeline is not perturbed).
- * vo_kernel_time_ms() waits for the stream, then returns the mean duration in
- * milliseconds over the launches recorded since timing was (re-)enabled and
- * their number in *launches; -1 if none.  Groups: */
+/* Kernel timing with HIP events recorded on the context's stream.
+ * vo_set_timing(ctx, groups) takes a bit mask (1 << VO_T_*, VO_T_ALL for every
+ * group, 0 to switch timing off): every launch of a selected kernel group is
+ * then bracketed by a fresh event pair.  Nothing waits on the events, but each
+ * bracket costs about 10 us of stream time, so select only what is needed
+ * inside a throughput measurement.  vo_kernel_time_ms() waits for the stream,
+ * then returns the mean duration in milliseconds over the launches recorded
+ * since the last vo_set_timing() and their number in *launches; -1 if none.
+ * Groups: */
 enum {
     VO_T_RESIZE = 0,   /* the seven pyramid resize launches of one detect call */
     VO_T_FAST = 1,     /* FAST-9 + NMS + border filter, all levels */
@@ -78,9 +81,10 @@ enum {
     VO_T_KNN2 = 5,     /* Hamming top-2 */
     VO_T_RATIO = 6,    /* ratio test + compaction */
     VO_T_RANSAC = 7,   /* all RANSAC and pose kernels of one call */
-    VO_T_COUNT = 8
+    VO_T_COUNT = 8,
+    VO_T_ALL = (1 << 8) - 1
 };
-int vo_set_timing(vo_ctx* ctx, int enabled);
+int vo_set_timing(vo_ctx* ctx, int groups);
 float vo_kernel_time_ms(vo_ctx* ctx, int group, int* launches);
 
 /* --- detect_features / detect_keypoints_only -------------------------------

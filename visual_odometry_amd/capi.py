@@ -116,8 +116,12 @@ class Context:
     def sync(self):
         self._check(self.lib.vo_sync(self.h), "vo_sync")
 
-    def set_timing(self, on=True):
-        self.lib.vo_set_timing(self.h, int(on))
+    def set_timing(self, on=True, groups=None):
+        """Brackets the launches of the named kernel groups (default: all) with HIP events."""
+        mask = 0
+        if on:
+            mask = (1 << len(T_GROUPS)) - 1 if groups is None else sum(1 << T_GROUPS.index(g) for g in groups)
+        self.lib.vo_set_timing(self.h, mask)
 
     def kernel_time_ms(self, group):
         """(mean ms per launch, launches) of a kernel group since timing was enabled."""

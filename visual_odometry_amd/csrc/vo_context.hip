@@ -40,7 +40,7 @@ static hipEvent_t take_event(vo_ctx* c) {
 }
 
 void t_begin(vo_ctx* c, int group) {
-    if (!c->timing || c->ev_used > 60000) return;
+    if (!((c->timing >> group) & 1u) || c->ev_used > 60000) return;
     hipEvent_t a = take_event(c), b = take_event(c);
     if (!a || !b) return;
     c->ev_pairs[group].emplace_back(a, b);
@@ -48,7 +48,7 @@ void t_begin(vo_ctx* c, int group) {
 }
 
 void t_end(vo_ctx* c, int group) {
-    if (!c->timing || c->ev_pairs[group].empty()) return;
+    if (!((c->timing >> group) & 1u) || c->ev_pairs[group].empty()) return;
     (void)hipEventRecord(c->ev_pairs[group].back().second, c->stream);
 }
 
@@ -101,10 +101,10 @@ extern "C" int vo_sync(vo_ctx* c) {
     return VO_OK;
 }
 
-extern "C" int vo_set_timing(vo_ctx* c, int enabled) {
+extern "C" int vo_set_timing(vo_ctx* c, int groups) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    c->timing = enabled != 0;
+    c->timing = (unsigned)groups & (unsigned)VO_T_ALL;
     for (auto& v : c->ev_pairs) v.clear();
     c->ev_used = 0;
     return VO_OK;

@@ -61,7 +61,7 @@ struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    bool timing = false;
+    unsigned timing = 0;   // bit g: kernel group g is bracketed by events
     std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)
     size_t ev_used = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[VO_T_COUNT];
