@@ -736,124 +736,227 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
     return count;
 }
 
-// ---- sixteen lanes per hypothesis: root search and refinement
-// After the elimination (one lane per hypothesis, sA in LDS) the serial part of a
-// hypothesis is the root search (nine derivative levels, each a safeguarded Newton per
-// monotone piece) and the refinement of up to ten candidates.  Both are spread over a
-// group of SG = 16 consecutive lanes: lane g of the group owns the g-th monotone piece of a
-// level, then the g-th root.  The outcome equals the one-lane routines' (same operations
-// per piece, the same ordered bookkeeping).
-constexpr int SG = 16;
-constexpr int SOLVE_THREADS = ST * SG;
-// What the front end (one lane per hypothesis) hands to the root search: determinant
-// polynomial, the three reduced constraint rows, the null-space basis; [0] = 1 if usable.
+// ---- root search and refinement, work items flattened over a workgroup's hypotheses
+// After the elimination (one lane per hypothesis) what is left of a hypothesis is the root
+// search - nine derivative levels, each a safeguarded Newton per monotone piece - and the
+// refinement of up to ten candidates.  A polynomial of degree ten has few real roots, so a
+// hypothesis offers only a handful of pieces per level and three or four candidates: the
+// back end therefore takes HB hypotheses per workgroup, numbers all their pieces (then all
+// their candidates) consecutively and hands one to each lane.  The outcome equals the
+// one-lane routines' (same operations per piece, the same ordered bookkeeping).
+constexpr int HB = 64;            // hypotheses per workgroup of the back end
+constexpr int BACK_THREADS = 512;   // eight wavefronts: one sweep covers a level's pieces, two waves per SIMD overlap
+// What the front end hands over: determinant polynomial, the three reduced constraint rows,
+// the null-space basis; [0] = 1 if usable.
 constexpr int HYP_REC = 88;   // doubles: flag, cf[11], bm[3][13], EE[4][9], one pad
-struct RootScratch {
-    double rt[ST][2][12];       // the two alternating root lists
-    double cand[ST][SG][4];     // per piece: end point that is an exact zero, bracketed root,
-    uint8_t ctype[ST][SG][4];   // touching extremum, final end point (0 = none)
+constexpr int PIECES = 11;    // at most ten roots of the next derivative -> eleven pieces
+
+struct BackShared {
+    double cf[HB][11];
+    double list[HB][2][12];      // the two alternating root lists
+    double px[HB][PIECES];       // bracketed root of a piece
+    double bound[HB];            // root bound R of the current level
+    double Ev[HB][kMaxModels][9];
+    uint8_t ptype[HB][12];       // per piece: 1 left end is an exact zero, 2 bracketed root,
+                                 // 4 right end is a touching extremum
+    uint8_t acc[HB][12];         // candidate settled on a solution
+    uint16_t close[HB][12];      // bit m: candidate m < r settled within 1e-7 of candidate r
+    uint16_t kept[HB];           // candidates that become models
+    uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
+    int16_t np[HB];              // roots in the current list
+    uint8_t levels[HB];          // 1: the hypothesis runs the nine levels
+    int total;
+#ifdef VO_PHASE_TIMING
+    int dbg_max[11], dbg_sum[11], dbg_n[11], dbg_smax[11], dbg_items[11];
+#endif
 };
 
-__device__ __forceinline__ void group_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ uint32_t group_ballot(bool p, int lane) {
-    return (uint32_t)(__ballot(p) >> (lane & 48)) & 0xFFFFu;
+// Numbers the work items of the workgroup: hypothesis h offers cnt items.  Called by the
+// first wavefront (lane = hypothesis); the map is valid after the next barrier.
+__device__ __forceinline__ void number_items(BackShared& sh, int h, int cnt) {
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o);
+        if (h >= o) incl += v;
+    }
+    const int off = incl - cnt;
+    for (int g = 0; g < cnt; ++g) sh.map[off + g] = (uint16_t)(h | (g << 8));
+    if (h == 63) sh.total = incl;
 }
 
-// One derivative level (degree DEG) for a group: sP holds the np roots of the next
-// derivative, the roots of this one go to sC (ascending); returns their number.
+// One derivative level (degree DEG) for the whole workgroup: list `si` holds the roots of the
+// next derivative, the roots of this one go to list 1 - si (ascending).
 template <int DEG>
-__device__ __forceinline__ int roots_level_group(const double* c, const double* sP, int np, double* sC, double* scand,
-                                                 uint8_t* stype, int g, int lane) {
-    constexpr int J = 10 - DEG;
-    double d[DEG + 1], dd[DEG];
+__device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
+    const int tid = threadIdx.x;
+    if (tid < 64) number_items(sh, tid, sh.levels[tid] ? sh.np[tid] + 1 : 0);
+    __syncthreads();
+    const int total = sh.total;
+#ifdef VO_PHASE_TIMING
+    if (tid == 0) sh.dbg_items[DEG] = total;
+#endif
+    for (int item = tid; item < total; item += BACK_THREADS) {
+        const int h = sh.map[item] & 0xFF, g = sh.map[item] >> 8;
+        const int np = sh.np[h];
+        constexpr int J = 10 - DEG;
+        double d[DEG + 1], dd[DEG];
 #pragma unroll
-    for (int i = 0; i <= DEG; ++i) d[i] = c[i + J] * falling(i + J, J);
+        for (int i = 0; i <= DEG; ++i) d[i] = sh.cf[h][i + J] * falling(i + J, J);
 #pragma unroll
-    for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
-    // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
-    double R = 0;
+        for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
+        // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
+        double R = 0;
 #pragma unroll
-    for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i]));
-    R = R / fabs(d[DEG]) * (1.0 + 1e-12) + 1.0;
-    const bool act = g <= np;
-    const double a = (act && g > 0) ? fmin(fmax(sP[g - 1], -R), R) : -R;
-    const double b = (act && g < np) ? fmin(fmax(sP[g], -R), R) : R;
-    const double fa = horner<DEG>(d, a), fb = horner<DEG>(d, b);
-    const bool inc = act && b > a;
-    const bool cA = inc && fa == 0.0;
-    const bool cX = inc && fa != 0.0 && ((fa < 0) != (fb < 0)) && fb != 0.0;
-    double x = 0;
-    if (cX) {
-        double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
-        x = 0.5 * (a + b);
-        double dxold = fabs(b - a), dx = dxold;
-        double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
-        for (int it = 0; it < 100; ++it) {
-            if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
-                dxold = dx;
-                dx = 0.5 * (xh - xl);
-                x = xl + dx;
-            } else {
-                dxold = dx;
-                dx = f / df;
-                x -= dx;
-            }
-            if (fabs(dx) <= 4.0 * DBL_EPSILON * fmax(1.0, fabs(x))) break;
-            f = horner<DEG>(d, x);
-            df = horner<DEG - 1>(dd, x);
-            if (f == 0.0) break;
-            if (f < 0.0) xl = x; else xh = x;
+        for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i]));
+        R = R / fabs(d[DEG]) * (1.0 + 1e-12) + 1.0;
+        if (g == 0) sh.bound[h] = R;
+        const double* sP = sh.list[h][si];
+        // Inner pieces lie between two roots of the derivative.  The two outer pieces are
+        // unbounded: whether they hold a root follows from the sign at the inner end and the
+        // sign at infinity, and the far end of the bracket is found by stepping outwards with
+        // a step that grows fourfold (Newton from the middle of [end, +-R] would crawl, it
+        // gains only a factor (DEG-1)/DEG per step while far from the roots).
+        const bool left_open = g == 0, right_open = g == np;
+        double a, b, fa, fb;
+        if (!left_open) {
+            a = fmin(fmax(sP[g - 1], -R), R);
+            fa = horner<DEG>(d, a);
         }
-    }
-    bool cT = false;
-    if (DEG == 10 && act && g < np && fb != 0.0) {
-        // a local extremum that touches zero to rounding level is a double root: keep it
-        double ab = fabs(b), mag = fabs(d[DEG]);
+        if (!right_open) {
+            b = fmin(fmax(sP[g], -R), R);
+            fb = horner<DEG>(d, b);
+        }
+        const double bT = right_open ? 0.0 : b, fbT = right_open ? 0.0 : fb;   // inner right end, for the extremum test
+        const bool lead_neg = d[DEG] < 0;
+        bool at_pivot = false;   // monotone polynomial with a zero exactly at the pivot
+        if (left_open || right_open) {
+            double p, fp, dir;
+            if (left_open && right_open) {   // no extremum at all: monotone, pivot at 0
+                p = 0.0;
+                fp = d[0];
+                dir = ((fp < 0) != lead_neg) ? 1.0 : -1.0;   // towards the sign opposite to fp
+                at_pivot = fp == 0.0;
+            } else if (right_open) {
+                p = a; fp = fa; dir = 1.0;
+            } else {
+                p = b; fp = fb; dir = -1.0;
+            }
+            // sign of the polynomial at dir * infinity
+            const bool inf_neg = dir > 0 ? lead_neg : (lead_neg != ((DEG & 1) != 0));
+            double q = p, fq = fp;
+            if (fp != 0.0 && ((fp < 0) != inf_neg)) {
+                double step = 1e-3 * fmax(1.0, fabs(p));
+                for (int it = 0; it < 64; ++it) {
+#ifdef VO_PHASE_TIMING
+                    atomicMax(&sh.dbg_smax[DEG], it + 1);
+#endif
+                    double x = p + dir * step;
+                    if (fabs(x) > R) x = dir * R;
+                    double fx = horner<DEG>(d, x);
+                    if (fx == 0.0 || ((fx < 0) != (fp < 0)) || fabs(x) >= R) {
+                        p = q; fp = fq;   // last point on the near side
+                        q = x; fq = fx;
+                        break;
+                    }
+                    q = x; fq = fx;
+                    step *= 4.0;
+                }
+            }
+            // [p, q] (in the direction dir) is the bracket, or p == q if there is no root
+            if (dir > 0) { a = p; fa = fp; b = q; fb = fq; }
+            else { a = q; fa = fq; b = p; fb = fp; }
+        }
+        const bool inc = b > a;
+        const bool cA = inc && fa == 0.0 && !left_open;
+        const bool cX = at_pivot || (inc && ((fa != 0.0 && ((fa < 0) != (fb < 0)) && fb != 0.0) ||
+                                             (left_open && fa == 0.0) || (right_open && fb == 0.0)));
+        if (cX) {
+            double x;
+            if (at_pivot) x = 0.0;
+            else if (left_open && fa == 0.0) x = a;     // the probe hit the root exactly
+            else if (right_open && fb == 0.0) x = b;
+            else {
+                double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
+                x = 0.5 * (a + b);
+                double dxold = fabs(b - a), dx = dxold;
+                double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
+                // The roots of the derivatives only delimit pieces and the final roots are
+                // refined afterwards, so 1e-10 (1e-12 on the last level) relative is enough;
+                // pieces that converge linearly (a root next to an extremum) stop at 40 steps.
+                constexpr double tol = DEG < 10 ? 1e-10 : 1e-12;
+#ifdef VO_PHASE_TIMING
+                int its_dbg = 0;
+#endif
+                for (int it = 0; it < 40; ++it) {
+#ifdef VO_PHASE_TIMING
+                    ++its_dbg;
+#endif
+                    if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+                        dxold = dx;
+                        dx = 0.5 * (xh - xl);
+                        x = xl + dx;
+                    } else {
+                        dxold = dx;
+                        dx = f / df;
+                        x -= dx;
+                    }
+                    if (fabs(dx) <= tol * fmax(1.0, fabs(x))) break;
+                    f = horner<DEG>(d, x);
+                    df = horner<DEG - 1>(dd, x);
+                    if (f == 0.0) break;
+                    if (f < 0.0) xl = x; else xh = x;
+                }
+#ifdef VO_PHASE_TIMING
+                atomicMax(&sh.dbg_max[DEG], its_dbg); atomicAdd(&sh.dbg_sum[DEG], its_dbg); atomicAdd(&sh.dbg_n[DEG], 1);
+#endif
+            }
+            sh.px[h][g] = x;
+        }
+        bool cT = false;
+        if (DEG == 10 && !right_open && fbT != 0.0) {
+            // a local extremum that touches zero to rounding level is a double root: keep it
+            double ab = fabs(bT), mag = fabs(d[DEG]);
 #pragma unroll
-        for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-        cT = fabs(fb) <= 1e-6 * mag;
+            for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
+            cT = fabs(fbT) <= 1e-6 * mag;
+        }
+        sh.ptype[h][g] = (uint8_t)((cA ? 1 : 0) | (cX ? 2 : 0) | (cT ? 4 : 0));
     }
-    const bool cF = act && g == np && fb == 0.0;
-    const uint32_t mX = group_ballot(cX, lane);
-    const uint32_t mOther = group_ballot(cA || cT || cF, lane);
-    int nc;
-    if (DEG < 10 && mOther == 0) {
-        // only bracketed roots, none of them subject to merging: ordered compaction
-        if (cX) sC[__popc(mX & ((1u << g) - 1u))] = x;
-        nc = __popc(mX);
-    } else {
-        scand[g * 4 + 0] = a; stype[g * 4 + 0] = cA ? 1 : 0;
-        scand[g * 4 + 1] = x; stype[g * 4 + 1] = cX ? 2 : 0;
-        scand[g * 4 + 2] = b; stype[g * 4 + 2] = cT ? 3 : 0;
-        scand[g * 4 + 3] = b; stype[g * 4 + 3] = cF ? 4 : 0;
-        group_sync();
-        // the ordered bookkeeping of the one-lane routine, replayed by every lane
-        nc = 0;
+    __syncthreads();
+    // the ordered bookkeeping of the one-lane routine, one lane per hypothesis
+    if (tid < HB && sh.levels[tid]) {
+        const int h = tid, np = sh.np[h];
+        const double R = sh.bound[h];
+        const double* sP = sh.list[h][si];
+        double* sC = sh.list[h][1 - si];
+        int nc = 0;
         double last = 0;
-        for (int k = 0; k <= np; ++k) {
+        for (int g = 0; g <= np; ++g) {
+            const int ty = sh.ptype[h][g];
+            if (ty == 0) continue;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ty = stype[k * 4 + t];
-                if (ty == 0) continue;
-                const double v = scand[k * 4 + t];
+            for (int t = 0; t < 3; ++t) {
+                if (!((ty >> t) & 1)) continue;
+                double v;
+                if (t == 0) v = fmin(fmax(sP[g - 1], -R), R);    // never set for the first piece
+                else if (t == 1) v = sh.px[h][g];
+                else v = fmin(fmax(sP[g], -R), R);               // never set for the last piece
                 const bool near = nc > 0 && fabs(v - last) <= 1e-7 * fmax(1.0, fabs(v));
                 bool push;
-                if (ty == 1 || ty == 4) push = nc == 0 || last != v;
-                else if (ty == 2) push = !(DEG == 10 && near);
+                if (t == 0) push = nc == 0 || last != v;
+                else if (t == 1) push = !(DEG == 10 && near);
                 else push = !near;
                 if (push && nc < 10) {
-                    if (g == 0) sC[nc] = v;
+                    sC[nc] = v;
                     last = v;
                     ++nc;
                 }
             }
         }
+        sh.np[h] = (int16_t)nc;
     }
-    group_sync();
-    return nc;
+    __syncthreads();
 }
 
 // Front end of one hypothesis per lane (ST lanes per workgroup, the elimination matrix in
@@ -880,90 +983,148 @@ __device__ __forceinline__ void solve_front(bool active, const double* x1, const
     rec[0] = ok ? 1.0 : 0.0;
 }
 
-// Root search and refinement of one hypothesis by a group of SG lanes (h = group index in the
-// workgroup): reads the record, writes the models and their number.
-__device__ __forceinline__ void solve_back(const double* __restrict__ rec, RootScratch& rs, double* __restrict__ Es_group,
-                                           int32_t* __restrict__ nm_group) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int h = tid / SG, g = tid % SG;
-    int count = 0;
-    if (rec && rec[0] != 0.0) {   // uniform inside a group
-        double cf[11];
+// Back end for up to HB hypotheses (records rec0 + h * HYP_REC, h < count): writes the models
+// of hypothesis h to Es0 + h * kMaxModels * 9 and their number to nm0[h].
+#ifdef VO_PHASE_TIMING
+#define VO_TICK(k) do { if (threadIdx.x == 0) ticks[k] = clock64(); } while (0)
+#else
+#define VO_TICK(k) do { } while (0)
+#endif
+__device__ __forceinline__ void solve_back_block(BackShared& sh, int count, const double* __restrict__ rec0,
+                                                 double* __restrict__ Es0, int32_t* __restrict__ nm0) {
+    const int tid = threadIdx.x;
+#ifdef VO_PHASE_TIMING
+    long long ticks[16];
+    if (tid < 11) { sh.dbg_max[tid] = 0; sh.dbg_sum[tid] = 0; sh.dbg_n[tid] = 0; sh.dbg_smax[tid] = 0; sh.dbg_items[tid] = 0; }
+#endif
+    VO_TICK(0);
+    if (tid < HB) {
+        const int h = tid;
+        const double* rec = rec0 + (size_t)h * HYP_REC;
+        int np = 0;
+        bool run = false;
+        if (h < count && rec[0] != 0.0) {
+            double cf[11], cmax = 0;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) cf[i] = rec[1 + i];
-        double cmax = 0;
-#pragma unroll
-        for (int i = 0; i <= 10; ++i) cmax = fmax(cmax, fabs(cf[i]));
-        double* A = rs.rt[h][0];
-        double* B = rs.rt[h][1];
-        double* scand = &rs.cand[h][0][0];
-        uint8_t* stype = &rs.ctype[h][0][0];
-        int nr;
-        if (fabs(cf[10]) > 1e-14 * cmax) {
-            if (g == 0) A[0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
-            group_sync();
-            nr = roots_level_group<2>(cf, A, 1, B, scand, stype, g, lane);
-            nr = roots_level_group<3>(cf, B, nr, A, scand, stype, g, lane);
-            nr = roots_level_group<4>(cf, A, nr, B, scand, stype, g, lane);
-            nr = roots_level_group<5>(cf, B, nr, A, scand, stype, g, lane);
-            nr = roots_level_group<6>(cf, A, nr, B, scand, stype, g, lane);
-            nr = roots_level_group<7>(cf, B, nr, A, scand, stype, g, lane);
-            nr = roots_level_group<8>(cf, A, nr, B, scand, stype, g, lane);
-            nr = roots_level_group<9>(cf, B, nr, A, scand, stype, g, lane);
-            nr = roots_level_group<10>(cf, A, nr, B, scand, stype, g, lane);
-        } else {   // degree-deficient polynomial (rare): generic one-lane path
-            if (g == 0) {
-                double roots[10];
-                int n = real_roots(cf, roots);
-                for (int k = 0; k < n; ++k) B[k] = roots[k];
-                B[10] = (double)n;
+            for (int i = 0; i < 11; ++i) {
+                cf[i] = rec[1 + i];
+                sh.cf[h][i] = cf[i];
+                cmax = fmax(cmax, fabs(cf[i]));
             }
-            group_sync();
-            nr = (int)B[10];
+            if (fabs(cf[10]) > 1e-14 * cmax) {
+                sh.list[h][0][0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
+                np = 1;
+                run = true;
+            } else {   // degree-deficient polynomial (rare): generic one-lane path
+                double roots[10];
+                np = real_roots(cf, roots);
+                for (int k = 0; k < np; ++k) sh.list[h][1][k] = roots[k];
+            }
         }
-        // ---- candidate g: start values, refinement, acceptance
+        sh.np[h] = (int16_t)np;
+        sh.levels[h] = run ? 1 : 0;
+    }
+    __syncthreads();
+    VO_TICK(1);
+    roots_level_block<2>(sh, 0);
+    VO_TICK(2);
+    roots_level_block<3>(sh, 1);
+    roots_level_block<4>(sh, 0);
+    VO_TICK(3);
+    roots_level_block<5>(sh, 1);
+    roots_level_block<6>(sh, 0);
+    VO_TICK(4);
+    roots_level_block<7>(sh, 1);
+    roots_level_block<8>(sh, 0);
+    VO_TICK(5);
+    roots_level_block<9>(sh, 1);
+    VO_TICK(6);
+    roots_level_block<10>(sh, 0);   // the roots end up in list 1
+    VO_TICK(7);
+    // ---- one lane per candidate: start values, refinement, acceptance
+    if (tid < 64) number_items(sh, tid, sh.np[tid]);
+    __syncthreads();
+    const int total = sh.total;
+    for (int item = tid; item < total; item += BACK_THREADS) {
+        const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
+        const double* rec = rec0 + (size_t)h * HYP_REC;
+        const double z1 = sh.list[h][1][r];
+        double EE[4][9], bm[3][13], Ev[9], sx, sy;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int k = 0; k < 13; ++k) bm[q][k] = rec[12 + q * 13 + k];
         bool acc = false;
-        double Ev[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Ev[k] = 0;
-        if (g < nr) {
-            double z1 = B[g], sx, sy;
-            double EE[4][9], bm[3][13];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 13; ++k) bm[r][k] = rec[12 + r * 13 + k];
+        if (model_start(bm, z1, &sx, &sy)) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
-            if (model_start(bm, z1, &sx, &sy)) {
-                double res = polish_model_dev(EE, sx, sy, z1, Ev);
-                acc = res <= 1e-9;   // settled on a solution
+            double res = polish_model_dev(EE, sx, sy, z1, Ev);
+            acc = res <= 1e-9;   // settled on a solution
+            if (acc) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
             }
         }
-        // two starts that settled on the same solution count once: a candidate falls if an
-        // accepted earlier one is within 1e-7 (either sign); decided in root order
-        for (int m = 0; m + 1 < nr; ++m) {
-            const bool acc_m = __shfl((int)acc, m, SG) != 0;   // final: depends on candidates < m only
-            double dp = 0, dm = 0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                double em = __shfl(Ev[k], m, SG);
-                dp = fmax(dp, fabs(em - Ev[k]));
-                dm = fmax(dm, fabs(em + Ev[k]));
-            }
-            if (acc_m && g > m && fmin(dp, dm) < 1e-7) acc = false;
-        }
-        const uint32_t macc = group_ballot(acc, lane);
-        if (acc) {
-            double* o = Es_group + __popc(macc & ((1u << g) - 1u)) * 9;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) o[k] = Ev[k];
-        }
-        count = __popc(macc);
+        sh.acc[h][r] = acc ? 1 : 0;
     }
-    if (g == 0 && nm_group) *nm_group = count;
+    __syncthreads();
+    VO_TICK(8);
+    // Two starts that settled on the same solution count once: in root order, a candidate
+    // falls if a kept earlier one is within 1e-7 (either sign).  The comparisons run one
+    // lane per candidate, the ordered decision is bit arithmetic by one lane per hypothesis.
+    for (int item = tid; item < total; item += BACK_THREADS) {
+        const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
+        uint32_t bits = 0;
+        if (sh.acc[h][r]) {
+            double Ev[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Ev[k] = sh.Ev[h][r][k];
+            for (int m = 0; m < r; ++m) {
+                if (!sh.acc[h][m]) continue;
+                double dp = 0, dm = 0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    double em = sh.Ev[h][m][k];
+                    dp = fmax(dp, fabs(em - Ev[k]));
+                    dm = fmax(dm, fabs(em + Ev[k]));
+                }
+                if (fmin(dp, dm) < 1e-7) bits |= 1u << m;
+            }
+        }
+        sh.close[h][r] = (uint16_t)bits;
+    }
+    __syncthreads();
+    if (tid < HB && tid < count) {
+        const int h = tid, nr = sh.np[h];
+        uint32_t kept = 0;
+        for (int r = 0; r < nr; ++r)
+            if (sh.acc[h][r] && !(sh.close[h][r] & kept)) kept |= 1u << r;
+        sh.kept[h] = (uint16_t)kept;
+        nm0[h] = __popc(kept);
+    }
+    __syncthreads();
+    for (int item = tid; item < total; item += BACK_THREADS) {
+        const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
+        const uint32_t kept = sh.kept[h];
+        if (!((kept >> r) & 1u)) continue;
+        double* o = Es0 + ((size_t)h * kMaxModels + __popc(kept & ((1u << r) - 1u))) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = sh.Ev[h][r][k];
+    }
+#ifdef VO_PHASE_TIMING
+    VO_TICK(9);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 3) {
+        int items = sh.total;
+        printf("back: load %lld L2 %lld L3-4 %lld L5-6 %lld L7-8 %lld L9 %lld L10 %lld polish %lld dedupe %lld cand %d\n",
+               ticks[1] - ticks[0], ticks[2] - ticks[1], ticks[3] - ticks[2], ticks[4] - ticks[3], ticks[5] - ticks[4],
+               ticks[6] - ticks[5], ticks[7] - ticks[6], ticks[8] - ticks[7], ticks[9] - ticks[8], items);
+        for (int D = 2; D <= 10; ++D)
+            printf("  deg %d items %d brackets %d max_its %d mean_its %.1f search_max %d\n", D, sh.dbg_items[D], sh.dbg_n[D],
+                   sh.dbg_max[D], sh.dbg_n[D] ? (double)sh.dbg_sum[D] / sh.dbg_n[D] : 0.0, sh.dbg_smax[D]);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restrict__ st, const double* __restrict__ m,
@@ -987,18 +1148,16 @@ __global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restric
     solve_front(active, x1, x2, sA, recs + ((size_t)b * hr + h) * HYP_REC);
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
-                                                                   const double* __restrict__ recs,
-                                                                   double* __restrict__ models,
-                                                                   int32_t* __restrict__ nmodels) {
-    __shared__ RootScratch rs;
+__global__ __launch_bounds__(BACK_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
+                                                                  const double* __restrict__ recs,
+                                                                  double* __restrict__ models,
+                                                                  int32_t* __restrict__ nmodels) {
+    __shared__ BackShared sh;
     const int b = blockIdx.y;
     if (st[b].done) return;
-    const int hg = blockIdx.x * ST + threadIdx.x / SG;   // this group's hypothesis
-    const bool in_round = hg < hr;
-    const size_t slot = (size_t)b * hr + (in_round ? hg : 0);
-    solve_back(in_round ? recs + slot * HYP_REC : nullptr, rs, models + slot * kMaxModels * 9,
-               in_round ? nmodels + slot : nullptr);
+    const int h0 = blockIdx.x * HB;
+    const size_t slot = (size_t)b * hr + h0;
+    solve_back_block(sh, min(HB, hr - h0), recs + slot * HYP_REC, models + slot * kMaxModels * 9, nmodels + slot);
 }
 
 // The inlier test (float)(err) <= t2 without the division in the common case: the
@@ -1441,15 +1600,13 @@ __global__ __launch_bounds__(ST) void five_point_debug_front_kernel(const double
     solve_front(true, a, b, sA, recs + (size_t)h * HYP_REC);
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void five_point_debug_back_kernel(int count, const double* __restrict__ recs,
-                                                                              double* __restrict__ models,
-                                                                              int32_t* __restrict__ nmodels) {
-    __shared__ RootScratch rs;
-    const int hg = blockIdx.x * ST + threadIdx.x / SG;
-    const bool in_range = hg < count;
-    const size_t slot = in_range ? hg : 0;
-    solve_back(in_range ? recs + slot * HYP_REC : nullptr, rs, models + slot * kMaxModels * 9,
-               in_range ? nmodels + slot : nullptr);
+__global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int count, const double* __restrict__ recs,
+                                                                             double* __restrict__ models,
+                                                                             int32_t* __restrict__ nmodels) {
+    __shared__ BackShared sh;
+    const int h0 = blockIdx.x * HB;
+    solve_back_block(sh, min(HB, count - h0), recs + (size_t)h0 * HYP_REC, models + (size_t)h0 * kMaxModels * 9,
+                     nmodels + h0);
 }
 
 static int round_size(int round, int fixed) {
@@ -1509,7 +1666,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         if (next < 0) next = 0;
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
-        hipLaunchKernelGGL(solve_back_kernel, dim3((hr + ST - 1) / ST, batch), dim3(SOLVE_THREADS), 0, s, st, hr, recs,
+        hipLaunchKernelGGL(solve_back_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
                            models, nmodels);
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
@@ -1623,7 +1780,7 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     if ((rc = ensure(c, c->r_best, (size_t)count * HYP_REC * 8))) return rc;
     hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
                        d_in + (size_t)count * 10, count, (double*)c->r_best.p);
-    hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + ST - 1) / ST), dim3(SOLVE_THREADS), 0, c->stream, count,
+    hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream, count,
                        (const double*)c->r_best.p, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
