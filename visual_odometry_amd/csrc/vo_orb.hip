@@ -784,6 +784,7 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     const uint32_t ke0 = T0 | (T1 << 16), ke1 = T2 | (T3 << 16), ke2 = T4 | (T5 << 16), ke3 = T6;
     const uint32_t ko0 = T0 << 16, ko1 = T1 | (T2 << 16), ko2 = T3 | (T4 << 16), ko3 = T5 | (T6 << 16);
     const int vec_end = L.w & ~3;
+    const bool all_even = x0 + BT_W <= vec_end;
     uint8_t* out = blur + (size_t)img * g.blk_stride + L.off;   // blur block uses the same offsets
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -802,9 +803,14 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
             se[j] = udot2_u16(c0[j], ke0, udot2_u16(c1[j], ke1, udot2_u16(c2[j], ke2, udot2_u16(c3[j], ke3, 0u))));
             so[j] = udot2_u16(c0[j], ko0, udot2_u16(c1[j], ko1, udot2_u16(c2[j], ko2, udot2_u16(c3[j], ko3, 0u))));
             // sum / 65536 rounded half-to-even below vec_end, half-up from there on
-            uint32_t ev = (X + j) < vec_end ? 1u : 0u;
-            se[j] += 32768u - ev + (ev & (se[j] >> 16));
-            so[j] += 32768u - ev + (ev & (so[j] >> 16));
+            if (all_even) {   // workgroup-uniform: every tile but a level's last column of tiles
+                se[j] += 32767u + ((se[j] >> 16) & 1u);
+                so[j] += 32767u + ((so[j] >> 16) & 1u);
+            } else {
+                uint32_t ev = (X + j) < vec_end ? 1u : 0u;
+                se[j] += 32768u - ev + (ev & (se[j] >> 16));
+                so[j] += 32768u - ev + (ev & (so[j] >> 16));
+            }
         }
         // high halves -> i16 pairs -> saturated bytes
         uint32_t e01 = sat_pk_u8_i16(__builtin_amdgcn_perm(se[1], se[0], 0x07060302u));
