@@ -99,9 +99,9 @@ def main():
     ap.add_argument("--workload", default="c2_640x480_2000kp", choices=list(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled up to --pairs)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="contexts (stream + workspace) the steps rotate over; 2 lets one batch's "
-                         "latency-bound RANSAC overlap the next batch's detection")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts (streams + workspace) the steps rotate over; one context already "
+                         "overlaps a batch's RANSAC rounds (side stream) with the next batch's detection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     args = ap.parse_args()

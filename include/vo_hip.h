@@ -60,7 +60,8 @@ int vo_ctx_create(int device, vo_ctx** out);
 void vo_ctx_destroy(vo_ctx* ctx);
 /* Message of the last failing call on this context ("" if none). */
 const char* vo_last_error(const vo_ctx* ctx);
-/* hipStream_t the context enqueues on (as void*). */
+/* hipStream_t the context enqueues on (as void*); vo_pipeline_pairs_dev also
+ * uses a second, internal stream - see there. */
 void* vo_ctx_stream(vo_ctx* ctx);
 int vo_sync(vo_ctx* ctx);
 /* Kernel timing with HIP events recorded on the context's stream.
@@ -151,7 +152,10 @@ int vo_find_essential(vo_ctx* ctx, const float* p1, const float* p2, int n, cons
  * match_images_orb (ref:src/image_matcher.cpp:71-81) followed by estimate_motion
  * as the reference's main loop runs them (ref:src/main.cpp:162-170), with every
  * intermediate kept in HBM.  Pair p uses images 2p and 2p+1 of d_imgs.
- * d_results: n_pairs records in device memory. */
+ * d_results: n_pairs records in device memory.  The call only enqueues: the
+ * RANSAC rounds run on a second stream of the context so that the next call's
+ * detection overlaps them, and d_results is complete after vo_sync() (which
+ * waits for both streams; waiting on vo_ctx_stream() alone is not enough). */
 int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
                           size_t image_stride, int max_features, float ratio, const double K[4],
                           double threshold, double confidence, int fixed_iters,

@@ -16,6 +16,7 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 256;
     if (b.p) {
         VO_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->side) VO_HIP(c, hipStreamSynchronize(c->side));
         VO_HIP(c, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -47,14 +48,25 @@ void t_begin(vo_ctx* c, int group) {
     (void)hipEventRecord(a, c->stream);
 }
 
-void t_end(vo_ctx* c, int group) {
+void t_end_on(vo_ctx* c, int group, hipStream_t s) {
     if (!((c->timing >> group) & 1u) || c->ev_pairs[group].empty()) return;
-    (void)hipEventRecord(c->ev_pairs[group].back().second, c->stream);
+    (void)hipEventRecord(c->ev_pairs[group].back().second, s);
+}
+
+void t_end(vo_ctx* c, int group) { t_end_on(c, group, c->stream); }
+
+int join_side(vo_ctx* c) {
+    if (!c->side_busy) return VO_OK;
+    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_rdone, 0));
+    c->side_busy = false;
+    return VO_OK;
 }
 
 }  // namespace vo
 
 using namespace vo;
+
+extern "C" void vo_ctx_destroy(vo_ctx* c);
 
 extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (!out) return VO_ERR_INVALID;
@@ -65,8 +77,11 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return VO_ERR_HIP;
     vo_ctx* c = new vo_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_rdone, hipEventDisableTiming) != hipSuccess) {
+        vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
     *out = c;
@@ -77,6 +92,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
                       &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->m_top2,   &c->m_qidx,
@@ -87,6 +103,9 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev_pool)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_init) (void)hipEventDestroy(c->ev_init);
+    if (c->ev_rdone) (void)hipEventDestroy(c->ev_rdone);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -98,12 +117,15 @@ extern "C" void* vo_ctx_stream(vo_ctx* c) { return c ? (void*)c->stream : nullpt
 extern "C" int vo_sync(vo_ctx* c) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->side));
+    c->side_busy = false;
     return VO_OK;
 }
 
 extern "C" int vo_set_timing(vo_ctx* c, int groups) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->side));
     c->timing = (unsigned)groups & (unsigned)VO_T_ALL;
     for (auto& v : c->ev_pairs) v.clear();
     c->ev_used = 0;
@@ -113,7 +135,7 @@ extern "C" int vo_set_timing(vo_ctx* c, int groups) {
 extern "C" float vo_kernel_time_ms(vo_ctx* c, int group, int* launches) {
     if (launches) *launches = 0;
     if (!c || group < 0 || group >= VO_T_COUNT) return -1.f;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1.f;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->side) != hipSuccess) return -1.f;
     double sum = 0;
     int n = 0;
     for (auto& pr : c->ev_pairs[group]) {

@@ -60,6 +60,12 @@ struct DevBuf {
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // The RANSAC rounds of the batched pipeline run on a second stream so that the next
+    // batch's detection (main stream) overlaps them; ev_init orders side after main, ev_rdone
+    // main after side before anything reuses the RANSAC workspace.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_init = nullptr, ev_rdone = nullptr;
+    bool side_busy = false;
     std::string err;
     unsigned timing = 0;   // bit g: kernel group g is bracketed by events
     std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)
@@ -87,6 +93,9 @@ int fail(vo_ctx* c, int code, const std::string& msg);
 // Records the begin / end event of one launch of kernel group `group` (no-ops unless timing is on).
 void t_begin(vo_ctx* c, int group);
 void t_end(vo_ctx* c, int group);
+void t_end_on(vo_ctx* c, int group, hipStream_t s);   // end event on another stream of the context
+// Makes the main stream wait for work still running on the side stream.
+int join_side(vo_ctx* c);
 int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
 
 #define VO_HIP(c, call)                                                                   \
@@ -110,6 +119,6 @@ int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
                double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
-               int samples_cap);
+               int samples_cap, bool on_side);
 
 }  // namespace vo

@@ -54,8 +54,9 @@ extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pai
         return rc;
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, (const int32_t*)c->m_cnt.p, cap, n_pairs,
                          K, threshold, confidence, fixed_iters, d_results, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         0)))
+                         0, true)))
         return rc;
+    // (main stream, right behind the point normalisation: the counts are overwritten by the next batch)
     hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, d_results, cnt,
                        (const int32_t*)c->m_cnt.p, n_pairs);
     VO_HIP(c, hipGetLastError());

@@ -1618,8 +1618,10 @@ static int round_size(int round, int fixed) {
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
                double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
-               int samples_cap) {
+               int samples_cap, bool on_side) {
     if (batch <= 0) return VO_OK;
+    // The workspace below may still be in use by the previous call's rounds on the side stream.
+    if (int jrc = join_side(c)) return jrc;
     hipStream_t s = c->stream;
     RParams P;
     P.ifx = 1.0 / K[0];
@@ -1658,6 +1660,13 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int r0 = std::min(round_size(0, fixed_iters), total);
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
                        r0);
+    if (on_side) {
+        // point normalisation and the first samples stay on the main stream (they read the
+        // caller's match buffers); the rounds and the pose recovery move to the side stream
+        VO_HIP(c, hipEventRecord(c->ev_init, c->stream));
+        VO_HIP(c, hipStreamWaitEvent(c->side, c->ev_init, 0));
+        s = c->side;
+    }
     int h0 = 0;
     for (int round = 0; h0 < total; ++round) {
         int hr = std::min(round_size(round, fixed_iters), total - h0);
@@ -1676,7 +1685,11 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     }
     hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(4 * FIN_T), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
                        d_good);
-    t_end(c, VO_T_RANSAC);
+    t_end_on(c, VO_T_RANSAC, s);
+    if (on_side) {
+        VO_HIP(c, hipEventRecord(c->ev_rdone, c->side));
+        c->side_busy = true;
+    }
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -1709,7 +1722,7 @@ static int run_host_ransac(vo_ctx* c, const float* p1, const float* p2, int n, c
     }
     if (d_samples) VO_HIP(c, hipMemsetAsync(d_samples, 0xFF, log_bytes, c->stream));
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, nullptr, n, 1, K, threshold, confidence,
-                         fixed_iters, d_res, d_E, d_me, d_mp, d_good, d_samples, samples_cap)))
+                         fixed_iters, d_res, d_E, d_me, d_mp, d_good, d_samples, samples_cap, false)))
         return rc;
     VO_HIP(c, hipMemcpyAsync(res, d_res, sizeof(vo_pair_result), hipMemcpyDeviceToHost, c->stream));
     if (E) VO_HIP(c, hipMemcpyAsync(E, d_E, 72, hipMemcpyDeviceToHost, c->stream));
@@ -1769,6 +1782,7 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     if (count <= 0 || !x1 || !x2 || !Es || !n_models) return fail(c, VO_ERR_INVALID, "vo_debug_five_point: bad argument");
     VO_HIP(c, hipSetDevice(c->device));
     int rc;
+    if ((rc = join_side(c))) return rc;
     size_t in_b = (size_t)count * 10 * 8, out_b = (size_t)count * kMaxModels * 9 * 8;
     if ((rc = ensure(c, c->r_pts, 2 * in_b))) return rc;
     if ((rc = ensure(c, c->r_models, out_b))) return rc;
