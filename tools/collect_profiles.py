@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Copies the evidence of the last GPU runs from gpurun_out/ into profiles/ (bench line, rocprofv3
+kernel statistics, HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes).
+
+    python tools/collect_profiles.py r01_f
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+
+
+def latest(pattern):
+    return sorted(glob.glob(os.path.join(R, pattern), recursive=True), key=os.path.getmtime)[-1]
+
+
+def per_kernel(fn):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        agg[r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+d = json.load(open(os.path.join(R, "gpurun_out/bench_final.json")))
+shutil.copy(os.path.join(R, "gpurun_out/bench_final.json"), os.path.join(R, f"profiles/{tag}_bench_default.json"))
+stats = latest("gpurun_out/prof_default/**/*kernel_stats.csv")
+shutil.copy(stats, os.path.join(R, f"profiles/{tag}_kernel_stats_default.csv"))
+print("bench", round(d["value"]), "pairs/s,", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "ms by events")
+for r in list(csv.DictReader(open(stats)))[:8]:
+    print("  ", r["Name"][:44].ljust(44), r["Calls"], float(r["AverageNs"]) / 1e6, "ms", r["Percentage"], "%")
+
+fe = per_kernel(latest("gpurun_out/pmc_traffic/bench_FETCH_SIZE/**/*counter_collection.csv"))
+wr = per_kernel(latest("gpurun_out/pmc_traffic/bench_WRITE_SIZE/**/*counter_collection.csv"))
+cf = per_kernel(latest("gpurun_out/pmc_traffic/calib_FETCH_SIZE/**/*counter_collection.csv"))
+cw = per_kernel(latest("gpurun_out/pmc_traffic/calib_WRITE_SIZE/**/*counter_collection.csv"))
+groups = {"fast": ("fast_kernel", 1), "blur": ("blur_kernel", 1), "describe": ("describe_kernel", 1),
+          "resize": ("resize_kernel", 7)}   # seven resize launches per step
+out = {
+    "workload": "c2_640x480_2000kp", "pairs_per_step": 256,
+    "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+              "bench.py --steps 3 --warmup 1 --streams 1; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  Calibration "
+              f"(tools/calib_fetch, same passes): a 1 GiB read reports FETCH_SIZE {cf['read_dword']:.0f} KiB with dword "
+              f"loads and {cf['read_dwordx4']:.0f} KiB with dwordx4 loads (half the bytes), a 256 MiB dword write "
+              f"reports WRITE_SIZE {cw['write_dword']:.0f} KiB (exact).",
+    "bytes_per_launch": {g: int((2 * fe[k] + wr[k]) * 1024 * m) for g, (k, m) in groups.items()},
+    "kib_raw": {k: {"FETCH_SIZE": fe[k], "WRITE_SIZE": wr[k]} for k in sorted(fe) if k in wr},
+}
+json.dump(out, open(os.path.join(R, "profiles/pmc_traffic.json"), "w"), indent=1)
+print(out["bytes_per_launch"])
