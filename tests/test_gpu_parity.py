@@ -341,3 +341,55 @@ def test_pipeline_pairs_matches_oracle(ctx, oracle):
         assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"]
         assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01
         assert np.linalg.norm(r["t"] - o["t"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_pipeline_back_to_back_calls_are_independent(ctx):
+    """Calls only enqueue (the RANSAC rounds of one call overlap the detection of the next on a
+    second stream): a burst of calls with different batches, one sync at the end, must give each
+    batch the results it gets when run alone - also when an estimate_motion call (which shares
+    the RANSAC workspace) lands in the middle of the burst."""
+    import torch
+    from visual_odometry_amd import capi
+    batches = []
+    for s in range(4):
+        n_pairs = 2 + (s % 2)
+        frames = []
+        for p in range(n_pairs):
+            frames += list(synth.frame_pair(300 + 10 * s + p))
+        batches.append((n_pairs, torch.from_numpy(np.stack(frames)).cuda()))
+
+    def run(n_pairs, imgs, res):
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), n_pairs, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res.data_ptr())
+
+    alone = []
+    for n_pairs, imgs in batches:
+        res = torch.zeros(n_pairs * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        run(n_pairs, imgs, res)
+        ctx.sync()
+        alone.append(np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE).copy())
+        assert alone[-1]["valid"].all() and (alone[-1]["inliers"] > 50).all()
+
+    rng = np.random.default_rng(5)
+    p1 = rng.uniform(50, 590, (300, 2)).astype(np.float32)
+    p2 = p1 + rng.normal(0, 3, p1.shape).astype(np.float32)
+    ref_motion = ctx.estimate_motion(p1, p2, TUM_K)
+
+    outs = [torch.zeros(n * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for n, _ in batches]
+    for rep in range(3):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        run(*batches[0], outs[0])
+        run(*batches[1], outs[1])
+        mid = ctx.estimate_motion(p1, p2, TUM_K)   # host-blocking call on the shared workspace
+        run(*batches[2], outs[2])
+        run(*batches[3], outs[3])
+        ctx.sync()
+        for o, a in zip(outs, alone):
+            got = np.frombuffer(o.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+            assert got.tobytes() == a.tobytes()
+        for k in ("valid", "inliers"):
+            assert mid[k] == ref_motion[k]
+        assert np.array_equal(mid["R"], ref_motion["R"]) and np.array_equal(mid["t"], ref_motion["t"])
