@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
         uint32_t k0[QPL], k1[QPL];
 #pragma unroll
         for (int k = 0; k < QPL; ++k) k0[k] = k1[k] = 0xFFFFFFFFu;
+        uint32_t thr[QPL];   // distance of the current second best (0xFFFF while there is none)
+#pragma unroll
+        for (int k = 0; k < QPL; ++k) thr[k] = 0xFFFFu;
         for (int t0 = 0; t0 < cn; t0 += MT_ROWS) {
             __syncthreads();
             if (t0 + tid < cn) {
@@ -87,18 +90,24 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
             __syncthreads();
             const int r0 = wave * 64;
             const int rn = min(max(cn - t0 - r0, 0), 64);
-            auto row_step = [&](const uint4& ta, const uint4& tc, uint32_t j) {
+            // distance of every query of this lane to one train row
+            auto row_dist = [&](const uint4& ta, const uint4& tc, uint32_t* d) {
 #pragma unroll
                 for (int k = 0; k < QPL; ++k) {
-                    uint32_t d = bcnt_acc(qr[k][0] ^ ta.x, 0u);
-                    d = bcnt_acc(qr[k][1] ^ ta.y, d);
-                    d = bcnt_acc(qr[k][2] ^ ta.z, d);
-                    d = bcnt_acc(qr[k][3] ^ ta.w, d);
-                    d = bcnt_acc(qr[k][4] ^ tc.x, d);
-                    d = bcnt_acc(qr[k][5] ^ tc.y, d);
-                    d = bcnt_acc(qr[k][6] ^ tc.z, d);
-                    d = bcnt_acc(qr[k][7] ^ tc.w, d);
-                    uint32_t key = (d << 16) | j;
+                    uint32_t v = bcnt_acc(qr[k][0] ^ ta.x, 0u);
+                    v = bcnt_acc(qr[k][1] ^ ta.y, v);
+                    v = bcnt_acc(qr[k][2] ^ ta.z, v);
+                    v = bcnt_acc(qr[k][3] ^ ta.w, v);
+                    v = bcnt_acc(qr[k][4] ^ tc.x, v);
+                    v = bcnt_acc(qr[k][5] ^ tc.y, v);
+                    v = bcnt_acc(qr[k][6] ^ tc.z, v);
+                    d[k] = bcnt_acc(qr[k][7] ^ tc.w, v);
+                }
+            };
+            auto row_update = [&](const uint32_t* d, uint32_t j) {
+#pragma unroll
+                for (int k = 0; k < QPL; ++k) {
+                    uint32_t key = (d[k] << 16) | j;
                     k1[k] = med3u(k0[k], k1[k], key);
                     k0[k] = min(k0[k], key);
                 }
@@ -109,12 +118,34 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
             for (; r + 4 <= rn; r += 4) {   // four rows' broadcast reads in flight ahead of their use
                 uint4 a0 = tp[2 * r], c0 = tp[2 * r + 1], a1 = tp[2 * r + 2], c1 = tp[2 * r + 3];
                 uint4 a2 = tp[2 * r + 4], c2 = tp[2 * r + 5], a3 = tp[2 * r + 6], c3 = tp[2 * r + 7];
-                row_step(a0, c0, jb + r);
-                row_step(a1, c1, jb + r + 1);
-                row_step(a2, c2, jb + r + 2);
-                row_step(a3, c3, jb + r + 3);
+                uint32_t d0[QPL], d1[QPL], d2[QPL], d3[QPL];
+                row_dist(a0, c0, d0);
+                row_dist(a1, c1, d1);
+                row_dist(a2, c2, d2);
+                row_dist(a3, c3, d3);
+                // Rows come in ascending index order, so a row enters a lane's top two only with a
+                // distance strictly below the current second best; once the lists have settled
+                // most row groups are skipped by the whole wavefront with four compares.
+                bool better = false;
+#pragma unroll
+                for (int k = 0; k < QPL; ++k)
+                    better |= (d0[k] < thr[k]) | (d1[k] < thr[k]) | (d2[k] < thr[k]) | (d3[k] < thr[k]);
+                if (__any(better)) {
+                    row_update(d0, jb + r);
+                    row_update(d1, jb + r + 1);
+                    row_update(d2, jb + r + 2);
+                    row_update(d3, jb + r + 3);
+#pragma unroll
+                    for (int k = 0; k < QPL; ++k) thr[k] = k1[k] >> 16;
+                }
             }
-            for (; r < rn; ++r) row_step(tp[2 * r], tp[2 * r + 1], jb + r);
+            for (; r < rn; ++r) {
+                uint32_t d[QPL];
+                row_dist(tp[2 * r], tp[2 * r + 1], d);
+                row_update(d, jb + r);
+            }
+#pragma unroll
+            for (int k = 0; k < QPL; ++k) thr[k] = k1[k] >> 16;
         }
 #pragma unroll
         for (int k = 0; k < QPL; ++k) {
