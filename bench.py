@@ -104,6 +104,7 @@ def main():
                          "overlaps a batch's RANSAC rounds (side stream) with the next batch's detection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--no-sequence", action="store_true")
     args = ap.parse_args()
 
     import torch   # before the HIP library: one HIP runtime for both
@@ -211,6 +212,32 @@ def main():
                      "kernel_group_ms_per_step_single_stream": kernel_ms,
                      "algorithmic_GBps_single_stream": {g: alg_bytes[g] / (kernel_ms[g] * 1e-3) / 1e9 for g in alg_bytes}},
     }
+
+    if not args.no_sequence:
+        # the same pipeline fed as a video sequence: P + 1 consecutive frames -> P pairs, each frame
+        # detected once (what a streaming caller of the reference's main loop would use)
+        # (synthetic sequence: the two frames of the first pair alternate, so that every
+        # consecutive pair shows the same scene under a small motion)
+        seq = torch.from_numpy(np.stack([frames[i & 1] for i in range(P + 1)])).cuda()
+        res_seq = torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        reps = max(3, args.steps // 4)
+        for _ in range(2):
+            ctx.pipeline_sequence_dev(seq.data_ptr(), P + 1, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+                                      res_seq.data_ptr())
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.pipeline_sequence_dev(seq.data_ptr(), P + 1, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+                                      res_seq.data_ptr())
+        fence()
+        sd = (time.perf_counter() - t0) / reps
+        t = torch.tensor([sd], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line["sequence_mode"] = {"frames_per_step_per_gpu": P + 1, "value": P * world / float(t.item()),
+                                 "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                                 "note": "consecutive frames, every frame detected once (vo_pipeline_sequence_dev); "
+                                         "not the headline metric, which detects both images of every pair"}
 
     if not args.no_hamming:
         # second half of the metric: brute-force Hamming kNN(2), 65 536 x 65 536 descriptors

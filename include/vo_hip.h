@@ -161,6 +161,17 @@ int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int r
                           double threshold, double confidence, int fixed_iters,
                           vo_pair_result* d_results);
 
+/* The same for a video sequence: n_frames consecutive frames in d_imgs give the
+ * n_frames - 1 pairs (i, i+1), as the reference's main loop walks a directory
+ * (ref:src/main.cpp:152-184, which detects every frame twice, once per pair it
+ * belongs to).  Each frame is detected once and serves as the second image of
+ * one pair and the first of the next; results are those of
+ * vo_pipeline_pairs_dev on the same pairs. */
+int vo_pipeline_sequence_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_frames, int rows, int cols, int step,
+                             size_t image_stride, int max_features, float ratio, const double K[4],
+                             double threshold, double confidence, int fixed_iters,
+                             vo_pair_result* d_results);
+
 /* --- inspection (parity tests) ---------------------------------------------------
  * Copies pyramid level `level` of image `image` of the most recent detect call
  * (blurred != 0: the 7x7 Gaussian-blurred copy the descriptors sample) to

@@ -393,3 +393,29 @@ def test_pipeline_back_to_back_calls_are_independent(ctx):
         for k in ("valid", "inliers"):
             assert mid[k] == ref_motion[k]
         assert np.array_equal(mid["R"], ref_motion["R"]) and np.array_equal(mid["t"], ref_motion["t"])
+
+
+@pytest.mark.gpu
+def test_pipeline_sequence_equals_pairwise(ctx):
+    """A sequence of frames gives, for each consecutive pair, exactly the record the pair
+    pipeline gives for that pair (each frame is detected once instead of twice)."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = [synth.frame_pair(400)[0]]
+    for s in range(5):
+        frames.append(synth.frame_pair(400 + s)[1] if s % 2 == 0 else synth.frame_pair(401 + s)[0])
+    n = len(frames)
+    seq = torch.from_numpy(np.stack(frames)).cuda()
+    pairs = torch.from_numpy(np.stack([frames[i + k] for i in range(n - 1) for k in range(2)])).cuda()
+    r_seq = torch.zeros((n - 1) * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    r_pair = torch.zeros_like(r_seq)
+    ctx.pipeline_sequence_dev(seq.data_ptr(), n, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                              r_seq.data_ptr())
+    ctx.sync()
+    ctx.pipeline_pairs_dev(pairs.data_ptr(), n - 1, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                           r_pair.data_ptr())
+    ctx.sync()
+    a = np.frombuffer(r_seq.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    b = np.frombuffer(r_pair.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    assert (a["n_kp1"] > 500).all() and (a["n_matches"] >= 0).all()
+    assert a.tobytes() == b.tobytes()

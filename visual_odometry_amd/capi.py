@@ -24,7 +24,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
-    "vo_pipeline_pairs_dev", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
+    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
 
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac"]
@@ -71,6 +71,7 @@ def load():
     lib.vo_estimate_motion.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_find_essential.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
+    lib.vo_pipeline_sequence_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_debug_level.argtypes = [vp, i, i, i, vp, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
     lib.vo_debug_five_point.argtypes = [vp, vp, vp, i, vp, vp]
@@ -232,3 +233,11 @@ class Context:
         self._check(self.lib.vo_pipeline_pairs_dev(self.h, d_imgs, n_pairs, rows, cols, step, image_stride,
                                                    max_features, ratio, _p(Kd), threshold, confidence, fixed_iters,
                                                    d_results), "vo_pipeline_pairs_dev")
+
+    def pipeline_sequence_dev(self, d_imgs, n_frames, rows, cols, step, image_stride, max_features, ratio, K,
+                              threshold, confidence, fixed_iters, d_results):
+        """n_frames consecutive frames -> the n_frames - 1 pairs (i, i+1), each frame detected once."""
+        Kd = np.asarray(K, np.float64)
+        self._check(self.lib.vo_pipeline_sequence_dev(self.h, d_imgs, n_frames, rows, cols, step, image_stride,
+                                                      max_features, ratio, _p(Kd), threshold, confidence,
+                                                      fixed_iters, d_results), "vo_pipeline_sequence_dev")

@@ -6,12 +6,14 @@
 
 namespace vo {
 
+// image of pair p: first = p * pair_step, second = first + 1 (pair_step 2: independent
+// pairs, 1: consecutive frames of a sequence)
 __global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32_t* __restrict__ kp_cnt,
-                                   const int32_t* __restrict__ nmatch, int n_pairs) {
+                                   const int32_t* __restrict__ nmatch, int n_pairs, int pair_step) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
-    res[p].n_kp1 = kp_cnt[2 * p];
-    res[p].n_kp2 = kp_cnt[2 * p + 1];
+    res[p].n_kp1 = kp_cnt[pair_step * p];
+    res[p].n_kp2 = kp_cnt[pair_step * p + 1];
     res[p].n_matches = nmatch[p];
 }
 
@@ -19,15 +21,12 @@ __global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32
 
 using namespace vo;
 
-extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
-                                     size_t image_stride, int max_features, float ratio, const double K[4],
-                                     double threshold, double confidence, int fixed_iters,
-                                     vo_pair_result* d_results) {
-    if (!c) return VO_ERR_INVALID;
-    if (n_pairs <= 0 || rows <= 0 || cols <= 0 || step < cols || max_features <= 0 || !d_imgs || !K || !d_results)
-        return fail(c, VO_ERR_INVALID, "vo_pipeline_pairs_dev: bad argument");
+// Shared body: n_images frames, pair p = (p * pair_step, p * pair_step + 1).
+static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
+                        int step, size_t image_stride, int max_features, float ratio, const double K[4],
+                        double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
     VO_HIP(c, hipSetDevice(c->device));
-    int n_images = 2 * n_pairs, rc;
+    int rc;
     if ((rc = orb_prepare(c, n_images, rows, cols, step, image_stride, max_features))) return rc;
     const int cap = c->g.kp_stride;   // quota + slack of every level: the detector cannot return more
     if ((rc = ensure(c, c->p_kps, (size_t)n_images * cap * sizeof(vo_keypoint)))) return rc;
@@ -45,11 +44,12 @@ extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pai
     uint8_t* desc = (uint8_t*)c->p_desc.p;
     int32_t* cnt = (int32_t*)c->p_cnt.p;
     if ((rc = orb_run(c, d_imgs, kps, desc, cap, cnt))) return rc;
-    if ((rc = knn2_launch(c, desc, cnt, 2, cap, (size_t)2 * cap * 32, desc + (size_t)cap * 32, cnt + 1, cap,
-                          (size_t)2 * cap * 32, n_pairs, (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
+    const size_t dstride = (size_t)pair_step * cap * 32;
+    if ((rc = knn2_launch(c, desc, cnt, pair_step, cap, dstride, desc + (size_t)cap * 32, cnt + 1, cap, dstride, n_pairs,
+                          (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
         return rc;
-    if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, cnt, 2, cap, n_pairs, ratio,
-                           kps, kps + cap, (size_t)2 * cap, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p,
+    if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, cnt, pair_step, cap, n_pairs,
+                           ratio, kps, kps + cap, (size_t)pair_step * cap, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p,
                            (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p)))
         return rc;
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, (const int32_t*)c->m_cnt.p, cap, n_pairs,
@@ -58,7 +58,29 @@ extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pai
         return rc;
     // (main stream, right behind the point normalisation: the counts are overwritten by the next batch)
     hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, d_results, cnt,
-                       (const int32_t*)c->m_cnt.p, n_pairs);
+                       (const int32_t*)c->m_cnt.p, n_pairs, pair_step);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
+}
+
+extern "C" int vo_pipeline_pairs_dev(vo_ctx* c, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
+                                     size_t image_stride, int max_features, float ratio, const double K[4],
+                                     double threshold, double confidence, int fixed_iters,
+                                     vo_pair_result* d_results) {
+    if (!c) return VO_ERR_INVALID;
+    if (n_pairs <= 0 || rows <= 0 || cols <= 0 || step < cols || max_features <= 0 || !d_imgs || !K || !d_results)
+        return fail(c, VO_ERR_INVALID, "vo_pipeline_pairs_dev: bad argument");
+    return pipeline_run(c, d_imgs, 2 * n_pairs, n_pairs, 2, rows, cols, step, image_stride, max_features, ratio, K,
+                        threshold, confidence, fixed_iters, d_results);
+}
+
+extern "C" int vo_pipeline_sequence_dev(vo_ctx* c, const uint8_t* d_imgs, int n_frames, int rows, int cols, int step,
+                                        size_t image_stride, int max_features, float ratio, const double K[4],
+                                        double threshold, double confidence, int fixed_iters,
+                                        vo_pair_result* d_results) {
+    if (!c) return VO_ERR_INVALID;
+    if (n_frames < 2 || rows <= 0 || cols <= 0 || step < cols || max_features <= 0 || !d_imgs || !K || !d_results)
+        return fail(c, VO_ERR_INVALID, "vo_pipeline_sequence_dev: bad argument");
+    return pipeline_run(c, d_imgs, n_frames, n_frames - 1, 1, rows, cols, step, image_stride, max_features, ratio, K,
+                        threshold, confidence, fixed_iters, d_results);
 }
