@@ -42,5 +42,20 @@ private:
     std::optional<E> e_;
 };
 
+// value-less flavour: success or an error
+template <typename E>
+class expected<void, E> {
+public:
+    expected() = default;
+    template <typename G> expected(unexpected<G> u) : e_(E(std::move(u).value())) {}   // NOLINT
+    [[nodiscard]] bool has_value() const noexcept { return !e_.has_value(); }
+    explicit operator bool() const noexcept { return has_value(); }
+    void value() const { if (e_) throw std::logic_error("expected holds an error"); }
+    E const& error() const { return *e_; }
+
+private:
+    std::optional<E> e_;
+};
+
 }  // namespace tl
 #endif

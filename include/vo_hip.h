@@ -172,6 +172,14 @@ int vo_pipeline_sequence_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_frames, i
                              double threshold, double confidence, int fixed_iters,
                              vo_pair_result* d_results);
 
+/* Host-buffer form: n_frames images in host memory (row pitch `step`, image
+ * pitch image_stride), n_frames - 1 records out; returns when they are written.
+ * What a directory-walking caller (ref:src/main.cpp:152-184) feeds a batch at a
+ * time, re-sending the last frame of one batch as the first of the next. */
+int vo_pipeline_sequence(vo_ctx* ctx, const uint8_t* imgs, int n_frames, int rows, int cols, int step,
+                         size_t image_stride, int max_features, float ratio, const double K[4],
+                         double threshold, double confidence, int fixed_iters, vo_pair_result* results);
+
 /* --- inspection (parity tests) ---------------------------------------------------
  * Copies pyramid level `level` of image `image` of the most recent detect call
  * (blurred != 0: the 7x7 Gaussian-blurred copy the descriptors sample) to

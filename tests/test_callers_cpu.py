@@ -1,0 +1,130 @@
+"""Callers either side of the hot path, host-only: the trajectory cases of the reference's
+tests/test_trajectory.cpp and the image loader's contract (tests/test_image_loader.cpp: sorted
+scan, rgb.txt timestamps, error strings), with the PNG/PGM decoders checked pixel by pixel
+against Pillow.  Colour-to-gray uses the BT.601 fixed-point weights; OpenCV's imread is not
+available to compare with, so that reduction is unpinned against the reference."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "test_callers")
+
+
+def _fnv(arr):
+    h = 1469598103934665603
+    for v in arr.reshape(-1).tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _gray(rgb):
+    rgb = rgb.astype(np.int64)
+    return ((rgb[..., 0] * 4899 + rgb[..., 1] * 9617 + rgb[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def _adam7_png(gray):
+    """8-bit gray Adam7-interlaced PNG written by hand (Pillow cannot write interlaced files)."""
+    h, w = gray.shape
+    raw = b""
+    for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        sub = gray[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        prev = np.zeros(sub.shape[1], np.int64)
+        for k, row in enumerate(sub):
+            ft = k % 5   # exercise every filter type
+            cur = row.astype(np.int64)
+            left = np.concatenate([[0], cur[:-1]])
+            ul = np.concatenate([[0], prev[:-1]])
+            if ft == 0: pred = np.zeros_like(cur)
+            elif ft == 1: pred = left
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (left + prev) >> 1
+            else:
+                p = left + prev - ul
+                pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            raw += bytes([ft]) + ((cur - pred) & 0xFF).astype(np.uint8).tobytes()
+            prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 1)
+    z = zlib.compress(raw)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    from PIL import Image
+    root = tmp_path_factory.mktemp("seq")
+    d = root / "rgb"
+    d.mkdir()
+    rng = np.random.default_rng(11)
+    expect = {}
+    g8 = rng.integers(0, 256, (23, 37), dtype=np.uint8)
+    Image.fromarray(g8).save(d / "00_gray8.png")
+    expect["00_gray8.png"] = g8
+    rgb = rng.integers(0, 256, (19, 41, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(d / "01_rgb.png")
+    expect["01_rgb.png"] = _gray(rgb)
+    g16 = rng.integers(0, 65536, (17, 29), dtype=np.uint16)
+    Image.fromarray(g16).save(d / "02_gray16.png")
+    expect["02_gray16.png"] = (g16 >> 8).astype(np.uint8)
+    pal = Image.fromarray(rgb).quantize(16)
+    pal.save(d / "03_palette.PNG")
+    expect["03_palette.PNG"] = _gray(np.asarray(pal.convert("RGB")))
+    bw = rng.integers(0, 2, (13, 21), dtype=np.uint8).astype(bool)
+    Image.fromarray(bw).save(d / "04_bilevel.png")
+    expect["04_bilevel.png"] = (bw * 255).astype(np.uint8)
+    rgba = rng.integers(0, 256, (9, 11, 4), dtype=np.uint8)
+    Image.fromarray(rgba, "RGBA").save(d / "05_rgba.png")
+    expect["05_rgba.png"] = _gray(rgba[..., :3])
+    la = rng.integers(0, 256, (9, 11, 2), dtype=np.uint8)
+    Image.fromarray(la, "LA").save(d / "06_la.png")
+    expect["06_la.png"] = la[..., 0]
+    inter = rng.integers(0, 256, (21, 19), dtype=np.uint8)
+    (d / "07_adam7.png").write_bytes(_adam7_png(inter))
+    expect["07_adam7.png"] = inter
+    assert np.array_equal(np.asarray(Image.open(d / "07_adam7.png")), inter)   # the hand-made file is a valid PNG
+    pgm = rng.integers(0, 256, (8, 12), dtype=np.uint8)
+    (d / "08_pgm.png").write_bytes(b"P5\n# comment\n12 8\n255\n" + pgm.tobytes())
+    expect["08_pgm.png"] = pgm
+    Image.fromarray(rgb).save(d / "09_photo.jpg", quality=90)
+    expect["09_photo.jpg"] = None          # JPEG: "Failed to load image"
+    (d / "10_broken.png").write_bytes(b"\x89PNG\r\n\x1a\nnot really")
+    expect["10_broken.png"] = None
+    (d / "notes.txt").write_text("ignored")
+    (root / "rgb.txt").write_text("# timestamp filename\n1305031102.175304 rgb/00_gray8.png\n1305031102.211214 rgb/01_rgb.png\n")
+    return str(d), expect
+
+
+def test_trajectory_and_loader(dataset):
+    d, expect = dataset
+    if not os.path.exists(BIN):   # fresh checkout: the binaries are built in-tree, not committed
+        subprocess.run(["make", "-C", ROOT, "tests/cpp/test_callers"], check=True, capture_output=True, timeout=900)
+    out = subprocess.run([BIN, d], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[-1] == "ALL PASSED"
+    assert lines[0] == f"count {len(expect)} timestamps 1"
+    seen = [l.split() for l in lines if l.startswith("image ")]
+    assert [s[1] for s in seen] == sorted(expect)          # sorted scan, other files ignored
+    for s in seen:
+        want = expect[s[1]]
+        if want is None:
+            assert s[2] == "error" and " ".join(s[3:7]) == "Failed to load image:"
+            continue
+        assert (int(s[2]), int(s[3])) == want.shape, s[1]
+        assert int(s[4], 16) == _fnv(want), s[1]
+    stamps = {s[1]: float(s[5]) for s in seen if len(s) == 6 and s[2] != "error"}
+    assert stamps["00_gray8.png"] == pytest.approx(1305031102.1753, abs=1e-3)
+    assert stamps["01_rgb.png"] == pytest.approx(1305031102.2112, abs=1e-3)
+    assert stamps["02_gray16.png"] == 0.0
+    # the pair walk stops at the first undecodable file (index 9)
+    assert lines[-2] == "pairs 8"

@@ -1,0 +1,64 @@
+"""The command-line front end (the reference tool's flags and output, ref:src/main.cpp:82-199)
+on a synthetic PNG sequence: its trajectory JSON must equal the poses composed in numpy from
+the records the C ABI returns for the same frames, whatever the batch size."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "visual_odometry_amd", "vo_main")
+K = synth.TUM_K
+
+
+@pytest.mark.gpu
+def test_cli_trajectory_matches_c_abi(ctx, tmp_path):
+    from PIL import Image
+    a, b = synth.frame_pair(700)
+    c, _ = synth.frame_pair(701)
+    frames = [a, b, a, b, c, a, b]          # pair (b, c) and (c, a) show unrelated scenes
+    d = tmp_path / "rgb"
+    d.mkdir()
+    lines = ["# timestamp filename"]
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(d / f"{i:04d}.png")
+        lines.append(f"{1000.5 + i:.6f} rgb/{i:04d}.png")
+    (tmp_path / "rgb.txt").write_text("\n".join(lines) + "\n")
+    cam = tmp_path / "cam.yaml"
+    cam.write_text("%YAML:1.0\n---\nfx: {}\nfy: {}\ncx: {}\ncy: {}\n".format(*K))
+
+    rec = ctx.pipeline_sequence(np.stack(frames), 2000, K)
+    poses = [(np.eye(3), np.zeros(3), 1000.5)]
+    for i, r in enumerate(rec):
+        if r["valid"]:
+            R0, t0, _ = poses[-1]
+            poses.append((R0 @ r["R"].reshape(3, 3), R0 @ r["t"] + t0, 1000.5 + i + 1))
+    assert rec["valid"][0] and rec["valid"][1]
+
+    for batch in (2, 64):
+        out = tmp_path / f"traj_{batch}.json"
+        run = subprocess.run([CLI, "--images", str(d), "--camera", str(cam), "--output", str(out), "--batch", str(batch)],
+                             capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert "Found 7 images" in run.stdout and "Timestamps loaded from rgb.txt" in run.stdout
+        assert "Using matcher: ORB" in run.stdout and "Processing 6 frame pairs..." in run.stdout
+        last = rec[-1]
+        tail = "" if last["valid"] else " [FAILED]"
+        assert f"  Frame     6/6 | Matches: {last['n_matches']} | Inliers: {last['inliers']}{tail}" in run.stdout
+        assert f"Processed 6 pairs, {int(rec['valid'].sum())} valid motions" in run.stdout
+        got = json.loads(out.read_text())["poses"]
+        assert len(got) == len(poses)
+        for g, (R, t, ts) in zip(got, poses):
+            assert g["timestamp"] == pytest.approx(ts, abs=1e-6)
+            assert np.allclose(np.array(g["rotation"]), R, atol=1e-9)
+            assert np.allclose(np.array(g["translation"]), t, atol=1e-9)
+
+    bad = subprocess.run([CLI, "--images", str(d), "--camera", str(tmp_path / "none.yaml")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Could not open camera file" in bad.stderr
+    bad = subprocess.run([CLI, "--images", str(d), "--camera", str(cam), "--matcher", "sift"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Unknown matcher: sift" in bad.stderr
+    assert subprocess.run([CLI], capture_output=True, text=True).returncode == 1

@@ -24,7 +24,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
-    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
+    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
 
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac"]
@@ -72,6 +72,7 @@ def load():
     lib.vo_find_essential.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
+    lib.vo_pipeline_sequence.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_debug_level.argtypes = [vp, i, i, i, vp, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
     lib.vo_debug_five_point.argtypes = [vp, vp, vp, i, vp, vp]
@@ -241,3 +242,13 @@ class Context:
         self._check(self.lib.vo_pipeline_sequence_dev(self.h, d_imgs, n_frames, rows, cols, step, image_stride,
                                                       max_features, ratio, _p(Kd), threshold, confidence,
                                                       fixed_iters, d_results), "vo_pipeline_sequence_dev")
+
+    def pipeline_sequence(self, frames, max_features, K, ratio=0.75, threshold=1.0, confidence=0.999, fixed_iters=0):
+        """Host arrays in (n_frames x H x W uint8), PAIR_DTYPE records of the n_frames - 1 pairs out."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        Kd = np.asarray(K, np.float64)
+        out = np.zeros(n - 1, PAIR_DTYPE)
+        self._check(self.lib.vo_pipeline_sequence(self.h, _p(frames), n, h, w, w, h * w, max_features, ratio, _p(Kd),
+                                                  threshold, confidence, fixed_iters, _p(out)), "vo_pipeline_sequence")
+        return out

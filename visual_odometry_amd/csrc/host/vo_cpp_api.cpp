@@ -13,6 +13,7 @@
 #include <visual_odometry/feature_matcher.hpp>
 #include <visual_odometry/image_matcher.hpp>
 #include <visual_odometry/motion_estimator.hpp>
+#include <visual_odometry/sequence_pipeline.hpp>
 
 #include "../../../include/vo_hip.h"
 
@@ -206,6 +207,40 @@ auto estimate_motion(std::span<cv::Point2f const> points1, std::span<cv::Point2f
     r.inliers = inliers;
     r.valid = true;
     return r;
+}
+
+auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& intrinsics, int max_features,
+                      float ratio_threshold, motion_estimator_config const& config) -> std::vector<sequence_step> {
+    std::vector<sequence_step> steps;
+    if (frames.size() < 2 || max_features <= 0) return steps;
+    int const rows = frames[0].rows, cols = frames[0].cols;
+    for (auto const& f : frames)
+        if (f.empty() || f.rows != rows || f.cols != cols || f.type() != CV_8UC1) return steps;
+    vo_ctx* c = ctx();
+    if (!c) return steps;
+    size_t const image_bytes = (size_t)rows * cols;
+    std::vector<uint8_t> packed(frames.size() * image_bytes);
+    for (size_t i = 0; i < frames.size(); ++i)
+        for (int r = 0; r < rows; ++r) std::memcpy(&packed[i * image_bytes + (size_t)r * cols], frames[i].ptr<uint8_t>(r), cols);
+    std::vector<vo_pair_result> rec(frames.size() - 1);
+    double const K[4] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy};
+    if (!ok(vo_pipeline_sequence(c, packed.data(), (int)frames.size(), rows, cols, cols, image_bytes, max_features,
+                                 ratio_threshold, K, config.ransac_threshold, config.ransac_confidence, 0, rec.data())))
+        return steps;
+    steps.resize(rec.size());
+    for (size_t i = 0; i < rec.size(); ++i) {
+        sequence_step& s = steps[i];
+        s.keypoints1 = rec[i].n_kp1;
+        s.keypoints2 = rec[i].n_kp2;
+        s.matches = rec[i].n_matches;
+        s.motion.valid = rec[i].valid != 0;
+        s.motion.inliers = rec[i].inliers;
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) s.motion.rotation(a, b) = rec[i].R[a * 3 + b];
+            s.motion.translation(a) = rec[i].t[a];
+        }
+    }
+    return steps;
 }
 
 }  // namespace visual_odometry

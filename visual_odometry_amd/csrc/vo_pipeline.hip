@@ -84,3 +84,25 @@ extern "C" int vo_pipeline_sequence_dev(vo_ctx* c, const uint8_t* d_imgs, int n_
     return pipeline_run(c, d_imgs, n_frames, n_frames - 1, 1, rows, cols, step, image_stride, max_features, ratio, K,
                         threshold, confidence, fixed_iters, d_results);
 }
+
+// Host-buffer form of vo_pipeline_sequence_dev: frames in, records out, synchronous.
+extern "C" int vo_pipeline_sequence(vo_ctx* c, const uint8_t* imgs, int n_frames, int rows, int cols, int step,
+                                    size_t image_stride, int max_features, float ratio, const double K[4],
+                                    double threshold, double confidence, int fixed_iters, vo_pair_result* results) {
+    if (!c) return VO_ERR_INVALID;
+    if (n_frames < 2 || rows <= 0 || cols <= 0 || step < cols || image_stride < (size_t)step * rows || max_features <= 0 ||
+        !imgs || !K || !results)
+        return fail(c, VO_ERR_INVALID, "vo_pipeline_sequence: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    const size_t img_bytes = (size_t)n_frames * image_stride, res_bytes = (size_t)(n_frames - 1) * sizeof(vo_pair_result);
+    if ((rc = ensure(c, c->st_img, img_bytes))) return rc;
+    if ((rc = ensure(c, c->r_res, res_bytes))) return rc;
+    VO_HIP(c, hipMemcpyAsync(c->st_img.p, imgs, img_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = pipeline_run(c, (const uint8_t*)c->st_img.p, n_frames, n_frames - 1, 1, rows, cols, step, image_stride,
+                           max_features, ratio, K, threshold, confidence, fixed_iters, (vo_pair_result*)c->r_res.p)))
+        return rc;
+    if ((rc = vo_sync(c))) return rc;   // both streams: the records are complete
+    VO_HIP(c, hipMemcpy(results, c->r_res.p, res_bytes, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
