@@ -128,3 +128,48 @@ def test_trajectory_and_loader(dataset):
     assert stamps["02_gray16.png"] == 0.0
     # the pair walk stops at the first undecodable file (index 9)
     assert lines[-2] == "pairs 8"
+
+
+def test_python_api_host_side(dataset, tmp_path):
+    """The Python module's host-side classes (names of the reference's bindings): loader contract,
+    decoders equal to the C++ ones, trajectory algebra and JSON text."""
+    from visual_odometry_amd import api
+    d, expect = dataset
+    with pytest.raises(RuntimeError, match="does not exist"):
+        api.image_loader.create(d + "/nope")
+    loader = api.image_loader.create(d)
+    assert len(loader) == len(expect) and loader.has_timestamps()
+    names = sorted(expect)
+    for i, n in enumerate(names):
+        if expect[n] is None:
+            with pytest.raises(RuntimeError, match="Failed to load image"):
+                loader.load_image(i)
+        else:
+            assert np.array_equal(loader.load_image(i), expect[n]), n
+    with pytest.raises(RuntimeError, match="out of range"):
+        loader.load_image(len(expect))
+    assert loader.get_timestamp(0) == pytest.approx(1305031102.175304)
+    assert sum(1 for _ in zip(range(8), loader)) == 8
+
+    t = api.Trajectory(1305031102.175304)
+    assert t.empty() and len(t) == 1
+    fwd = api.MotionEstimate(np.eye(3), [0, 0, 1], 100, True)
+    assert not t.add_motion(api.MotionEstimate()) and t.add_motion(fwd, 1305031102.211214)
+    Ry = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], float)
+    assert t.add_motion(api.MotionEstimate(Ry, [0, 0, 1], 50, True), 3.0) and t.add_motion(fwd, 4.0)
+    assert np.allclose(t.current_pose.translation, [1, 0, 2]) and bool(fwd) and not bool(api.MotionEstimate())
+    js = t.to_json()
+    assert js.startswith('{\n  "poses": [\n    {\n      "timestamp": 1305031102.1753039360,\n      "rotation": [\n        [1, 0, 0],\n')
+    assert js.endswith('      "translation": [1, 0, 2]\n    }\n  ]\n}\n')
+    import json
+    assert len(json.loads(js)["poses"]) == 4
+    t.save_to_json(tmp_path / "t.json")
+    assert (tmp_path / "t.json").read_text() == js
+    with pytest.raises(RuntimeError, match="Failed to open"):
+        t.save_to_json("/nonexistent/dir/t.json")
+    cam = tmp_path / "cam.yaml"
+    cam.write_text("%YAML:1.0\n---\nfx: 517.3\nfy: 516.5\ncx: 318.6\ncy: 255.3\n")
+    k = api.CameraIntrinsics.load_from_yaml(cam)
+    assert (k.fx, k.fy, k.cx, k.cy) == (517.3, 516.5, 318.6, 255.3) and k.camera_matrix()[0, 2] == 318.6
+    with pytest.raises(RuntimeError, match="Could not open camera file"):
+        api.CameraIntrinsics.load_from_yaml(tmp_path / "none.yaml")

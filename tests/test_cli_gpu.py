@@ -62,3 +62,29 @@ def test_cli_trajectory_matches_c_abi(ctx, tmp_path):
     bad = subprocess.run([CLI, "--images", str(d), "--camera", str(cam), "--matcher", "sift"], capture_output=True, text=True)
     assert bad.returncode == 1 and "Unknown matcher: sift" in bad.stderr
     assert subprocess.run([CLI], capture_output=True, text=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_python_api_matches_oracle(oracle):
+    """orb_matcher / estimate_motion / process_sequence under the reference bindings' names."""
+    from visual_odometry_amd import api
+    a, b = synth.frame_pair(710)
+    k = api.CameraIntrinsics(*K)
+    m = api.orb_matcher(1500, 0.75)
+    assert m.name == "ORB"
+    r = m.match_images(a, b)
+    ka, da = oracle.orb_detect(a, 1500)
+    kb, db = oracle.orb_detect(b, 1500)
+    qi, ti, _ = oracle.match(da, db)
+    assert r.num_matches == len(r) == len(qi) and np.array_equal(r.query_idx, qi) and np.array_equal(r.train_idx, ti)
+    assert np.array_equal(r.points1, np.stack([ka["x"][qi], ka["y"][qi]], 1))
+    mo = api.estimate_motion(r.points1, r.points2, k)
+    o = oracle.estimate_motion(r.points1, r.points2, K)
+    assert bool(mo) == o["valid"] and mo.inliers == o["inliers"] and np.allclose(mo.rotation, o["R"], atol=1e-8)
+    assert not api.estimate_motion(r.points1[:4], r.points2[:4], k)
+    assert api.orb_matcher().match_images(np.zeros((0, 0), np.uint8), b).num_matches == 0
+    steps = api.process_sequence(np.stack([a, b, a]), k, 1500)
+    assert len(steps) == 2 and steps[0].matches == len(qi) and steps[0].motion.inliers == mo.inliers
+    assert np.array_equal(steps[0].motion.rotation, mo.rotation)
+    with pytest.raises(RuntimeError):
+        api.process_sequence(np.stack([a]), k)
