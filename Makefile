@@ -7,7 +7,7 @@ HDRS := $(CSRC)/vo_internal.h $(CSRC)/orb_pattern.inc include/vo_hip.h
 OBJS := $(SRCS:.hip=.o)
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
 
-all: visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin tests/cpp/test_callers visual_odometry_amd/vo_main
+all: visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin tests/cpp/test_callers visual_odometry_amd/vo_main visual_odometry_amd/vo_benchmark
 
 %.o: %.hip $(HDRS)
 	$(HIPCC) $(FLAGS) -c $< -o $@
@@ -34,10 +34,13 @@ tests/cpp/test_callers: tests/cpp/test_callers.cpp visual_odometry_amd/libvisual
 visual_odometry_amd/vo_main: apps/vo_main.cpp visual_odometry_amd/libvisual_odometry_hip.so
 	$(CXX) -std=c++20 -O2 -Iinclude -o $@ apps/vo_main.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,visual_odometry_amd
 
+visual_odometry_amd/vo_benchmark: apps/vo_benchmark.cpp visual_odometry_amd/libvisual_odometry_hip.so
+	$(CXX) -std=c++20 -O2 -Iinclude -o $@ apps/vo_benchmark.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,visual_odometry_amd
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin tests/cpp/test_callers visual_odometry_amd/vo_main
+	rm -f $(OBJS) visual_odometry_amd/libvo_hip.so visual_odometry_amd/libvisual_odometry_hip.so tests/cpp/test_dropin tests/cpp/test_callers visual_odometry_amd/vo_main visual_odometry_amd/vo_benchmark
 
 .PHONY: all oracle clean

@@ -88,3 +88,33 @@ def test_python_api_matches_oracle(oracle):
     assert np.array_equal(steps[0].motion.rotation, mo.rotation)
     with pytest.raises(RuntimeError):
         api.process_sequence(np.stack([a]), k)
+
+
+@pytest.mark.gpu
+def test_benchmark_tool_json(ctx, tmp_path):
+    """The benchmark tool (flags and JSON keys of ref:benchmarks/benchmark_matchers.cpp:25-192)."""
+    from PIL import Image
+    a, b = synth.frame_pair(720)
+    frames = [a, b, a, b]
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(d / f"{i:03d}.png")
+    cam = tmp_path / "cam.yaml"
+    cam.write_text("%YAML:1.0\n---\nfx: {}\nfy: {}\ncx: {}\ncy: {}\n".format(*K))
+    out = tmp_path / "bench.json"
+    tool = os.path.join(ROOT, "visual_odometry_amd", "vo_benchmark")
+    run = subprocess.run([tool, "--images", str(d), "--camera", str(cam), "--output", str(out)], capture_output=True,
+                         text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Benchmarking ORB..." in run.stdout and "  Pair 3: " in run.stdout and "Results written to:" in run.stdout
+    js = json.loads(out.read_text())
+    rec = ctx.pipeline_sequence(np.stack(frames), 2000, K)
+    assert js["matcher"] == "ORB" and js["num_pairs"] == 3
+    assert js["total_matches"] == int(rec["n_matches"].sum()) and js["total_inliers"] == int(rec["inliers"].sum())
+    assert js["batched_total_inliers"] == js["total_inliers"]
+    assert js["avg_matches"] == pytest.approx(rec["n_matches"].mean(), abs=0.01)
+    assert js["avg_inlier_ratio"] == pytest.approx(rec["inliers"].sum() / rec["n_matches"].sum(), abs=1e-4)
+    assert js["avg_time_ms"] > 0 and js["batched_avg_time_ms"] > 0
+    for key in ("total_time_ms", "avg_inliers"):
+        assert key in js
