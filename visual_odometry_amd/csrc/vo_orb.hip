@@ -853,22 +853,19 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
     }
 }
 
-// Half a wavefront (32 lanes) per keypoint, two keypoints per wave, grid-stride over an
-// image's keypoints.  Intensity-centroid angle: the half-wave sweeps the 31x31 disc in
-// eight steps of four rows, lane = (row of the step, dword of the 32-byte row window); a
-// step is one unaligned dword load, the disc byte mask and two v_dot4_u32_u8 (sum and
-// column-weighted sum), the row weight is applied to the row sum.  The first lane of the
-// half writes the final keypoint, then lane t evaluates tests t, t+32, ..., t+224 and eight
-// ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
-__global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
-                                                       const uint8_t* __restrict__ pyr,
-                                                       const uint8_t* __restrict__ blur,
-                                                       const uint16_t* __restrict__ kp_x,
-                                                       const uint16_t* __restrict__ kp_y,
-                                                       const float* __restrict__ kp_resp,
-                                                       const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
-                                                       uint8_t* __restrict__ desc, int cap, int32_t* __restrict__ counts,
-                                                       uint32_t* __restrict__ flags) {
+// Orientation and keypoint records.  Half a wavefront (32 lanes) per keypoint, two keypoints
+// per wave, grid-stride over an image's keypoints.  Intensity-centroid angle: the half-wave
+// sweeps the 31x31 disc in eight steps of four rows, lane = (row of the step, dword of the
+// 32-byte row window); a step is one unaligned dword load, the disc byte mask and two
+// v_dot4_u32_u8 (sum and column-weighted sum), the row weight is applied to the row sum.  The
+// first lane of the half writes the final keypoint.
+__global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
+                                                     const uint8_t* __restrict__ pyr,
+                                                     const uint16_t* __restrict__ kp_x,
+                                                     const uint16_t* __restrict__ kp_y,
+                                                     const float* __restrict__ kp_resp,
+                                                     const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
+                                                     int cap, int32_t* __restrict__ counts, uint32_t* __restrict__ flags) {
     uint32_t work;
     if (!xcd_remap((uint32_t)bx * (uint32_t)g.n_images, &work)) return;
     const int img = (int)(work / (uint32_t)bx), blk = (int)(work - (uint32_t)img * (uint32_t)bx);
@@ -884,115 +881,107 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
         if (total > cap) atomicOr(flags, 4u);
     }
     const int n = min(total, cap);
-    // this lane's eight tests and disc masks are the same for every keypoint: fetch them once
-    int pat[8];
-    uint32_t amask[8];
+    uint32_t amask[8];   // this lane's disc masks are the same for every keypoint
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
-        amask[k] = d_angle_mask[k * 32 + hl];
-    }
+    for (int k = 0; k < 8; ++k) amask[k] = d_angle_mask[k * 32 + hl];
     const int rr = hl >> 3, dj = hl & 7;
     const uint32_t wcol = 0x03020100u + 0x04040404u * (uint32_t)dj;   // window byte index = u + 15
+    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
+        const bool live = o2 + half < n;          // an odd count leaves the last second half idle
+        const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
+        int l = 0, lstart = 0;
+#pragma unroll
+        for (int k = 1; k < kLevels; ++k) {
+            l += (oi >= start[k]);
+            lstart = (oi >= start[k]) ? start[k] : lstart;
+        }
+        const LevelGeom& L = g.L[l];
+        const size_t ib = (size_t)img * g.kp_stride + L.kp_off + (oi - lstart);
+        const int x = kp_x[ib], y = kp_y[ib];
+        int lpitch;
+        const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
+        // every address within 16 px of a keypoint is inside the level (keypoints keep a
+        // 31-px margin): all loads are issued unconditionally and masked afterwards
+        const uint8_t* p = lbase + (size_t)(y - kHalfPatch + rr) * lpitch + (x - kHalfPatch + 4 * dj);
+        uint32_t v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = load_u32_unaligned(p + (size_t)(4 * t) * lpitch);
+        uint32_t S = 0, X = 0;
+        int m01 = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint32_t val = v[t] & amask[t];
+            uint32_t rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
+            X = __builtin_amdgcn_udot4(val, wcol, X, false);
+            S += rs;
+            m01 += (4 * t - kHalfPatch + rr) * (int)rs;
+        }
+        int m10 = (int)X - kHalfPatch * (int)S;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+        if (hl == 0 && live) {
+            vo_keypoint k;
+            k.x = (float)x * L.scale;
+            k.y = (float)y * L.scale;
+            k.size = 31 * L.scale;
+            k.angle = fast_atan2_deg((float)m01, (float)m10);
+            k.response = kp_resp[ib];
+            k.octave = l;
+            k.class_id = -1;
+            kps[(size_t)img * cap + oi] = k;
+        }
+    }
+}
+
+// rBRIEF descriptors from the finished keypoint records.  Half a wavefront per keypoint: the
+// 37x37 blurred window around it goes to LDS with 13 dword loads per lane (ten sweeps of
+// 4 rows x 8 dwords, three of 16 rows x 2 dwords; all inside the level thanks to the 31-px
+// keypoint margin - gathering the 512 test points from global memory instead costs one L1 tag
+// look-up per lane and test), lane t evaluates tests t, t+32, ..., t+224 on it and eight
+// ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
+__global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ blur,
+                                                       const vo_keypoint* __restrict__ kps,
+                                                       const int32_t* __restrict__ counts, uint8_t* __restrict__ desc,
+                                                       int cap) {
+    uint32_t work;
+    if (!xcd_remap((uint32_t)bx * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)bx), blk = (int)(work - (uint32_t)img * (uint32_t)bx);
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int n = counts[img];
+    int pat[8];   // this lane's eight tests are the same for every keypoint
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
+    const int rr = hl >> 3, dj = hl & 7;
     const uint8_t* blur_img = blur + (size_t)img * g.blk_stride;
     // blurred window of +-18 px around the keypoint (the rotated test points stay inside:
     // the pattern's largest radius is 18.4), one per half-wave, rows padded to 40 bytes
     constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 40;
     __shared__ __attribute__((aligned(16))) uint8_t patch[8][DP_ROWS * DP_PITCH];
     uint8_t* my_patch = patch[(threadIdx.x >> 6) * 2 + half];
-    // keypoint o -> (level, slot in the level's list); the coordinates of the next round's
-    // keypoint are fetched one round ahead
-    auto locate = [&](int o2, bool* live, int* oi, int* l) -> size_t {
-        *live = o2 + half < n;                 // an odd count leaves the last second half idle
-        *oi = *live ? o2 + half : min(o2, max(n - 1, 0));   // (it repeats a neighbour's work, writes nothing)
-        int lv = 0, lstart = 0;
-#pragma unroll
-        for (int k = 1; k < kLevels; ++k) {
-            lv += (*oi >= start[k]);
-            lstart = (*oi >= start[k]) ? start[k] : lstart;
-        }
-        *l = lv;
-        return (size_t)img * g.kp_stride + g.L[lv].kp_off + (*oi - lstart);
-    };
-    int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2;
-    if (o2 >= n) return;
-    bool live;
-    int oi, l;
-    size_t ib = locate(o2, &live, &oi, &l);
-    int x = kp_x[ib], y = kp_y[ib];
-    for (; o2 < n; o2 += bx * 8) {
-        const bool live_c = live;
-        const int oi_c = oi, l_c = l, x_c = x, y_c = y;
-        const size_t ib_c = ib;
-        if (o2 + bx * 8 < n) {   // wave-uniform
-            ib = locate(o2 + bx * 8, &live, &oi, &l);
-            x = kp_x[ib];
-            y = kp_y[ib];
-        }
-        const LevelGeom& L = g.L[l_c];
-        // The window loads are issued first, together with the angle pass' loads: 37 rows of
-        // 40 bytes as ten sweeps of 4 rows x 8 dwords and three of 16 rows x 2 dwords.  All
-        // of it lies inside the level (31-px keypoint margin).  Gathering the 512 test points
-        // from global memory instead costs one L1 tag look-up per lane and test.
-        const float fx = (float)x_c * L.scale, fy = (float)y_c * L.scale;
+    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
+        const bool live = o2 + half < n;
+        const int oi = live ? o2 + half : o2;
+        const vo_keypoint kp = kps[(size_t)img * cap + oi];
+        const LevelGeom& L = g.L[kp.octave];
+        const float inv = 1.f / L.scale;
+        const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int pitch = L.pitch;
+        const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R);
         uint32_t pw[13];
-        if (desc) {
-            const float inv = 1.f / L.scale;
-            const int cx = __float2int_rn(fx * inv), cy = __float2int_rn(fy * inv);
-            const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R);
 #pragma unroll
-            for (int t = 0; t < 10; ++t)
-                pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(__mul24(min(4 * t + rr, DP_ROWS - 1), pitch) + 4 * dj)));
+        for (int t = 0; t < 10; ++t)
+            pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(__mul24(min(4 * t + rr, DP_ROWS - 1), pitch) + 4 * dj)));
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                pw[10 + t] = load_u32_unaligned(
-                    blur_img + (org + (uint32_t)(__mul24(min(16 * t + (hl >> 1), DP_ROWS - 1), pitch) + 32 + 4 * (hl & 1))));
-        }
-        float angle;
-        {
-            int lpitch;
-            const uint8_t* lbase = level_base(g, in, pyr, img, l_c, &lpitch);
-            // every address within 16 px of a keypoint is inside the level (keypoints keep a
-            // 31-px margin): all loads are issued unconditionally and masked afterwards
-            const uint8_t* p = lbase + (size_t)(y_c - kHalfPatch + rr) * lpitch + (x_c - kHalfPatch + 4 * dj);
-            uint32_t v[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[t] = load_u32_unaligned(p + (size_t)(4 * t) * lpitch);
-            uint32_t S = 0, X = 0;
-            int m01 = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                uint32_t val = v[t] & amask[t];
-                uint32_t rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
-                X = __builtin_amdgcn_udot4(val, wcol, X, false);
-                S += rs;
-                m01 += (4 * t - kHalfPatch + rr) * (int)rs;
-            }
-            int m10 = (int)X - kHalfPatch * (int)S;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                m10 += __shfl_xor(m10, o);
-                m01 += __shfl_xor(m01, o);
-            }
-            angle = fast_atan2_deg((float)m01, (float)m10);
-        }
-        if (hl == 0 && live_c) {
-            vo_keypoint k;
-            k.x = fx;
-            k.y = fy;
-            k.size = 31 * L.scale;
-            k.angle = angle;
-            k.response = kp_resp[ib_c];
-            k.octave = l_c;
-            k.class_id = -1;
-            kps[(size_t)img * cap + oi_c] = k;
-        }
-        if (!desc) continue;
-        float ar = angle * (float)(M_PI / 180.f);
+        for (int t = 0; t < 3; ++t)
+            pw[10 + t] = load_u32_unaligned(
+                blur_img + (org + (uint32_t)(__mul24(min(16 * t + (hl >> 1), DP_ROWS - 1), pitch) + 32 + 4 * (hl & 1))));
+        const float ar = kp.angle * (float)(M_PI / 180.f);
         double sd, cd;
         sincos_f64((double)ar, &sd, &cd);
-        float a = (float)cd, b = (float)sd;
+        const float a = (float)cd, b = (float)sd;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous keypoint's reads are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1022,7 +1011,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
             if (hl == k) mine = w;
         }
-        if (hl < 8 && live_c) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi_c) * 32 + hl * 4) = mine;
+        if (hl < 8 && live) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi) * 32 + hl * 4) = mine;
     }
 }
 
@@ -1268,10 +1257,12 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     }
     t_begin(c, VO_T_DESCRIBE);
     const int dbx = std::max((g.max_features + 31) / 32, 1);   // about four keypoint pairs per wavefront
-    hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
-                       (const uint8_t*)c->blur.p, (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p,
-                       (const float*)c->kp_resp.p, (const uint32_t*)c->kp_cnt.p, d_kps,
-                       d_desc, cap, d_counts, (uint32_t*)c->flags.p);
+    hipLaunchKernelGGL(orient_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
+                       (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p, (const float*)c->kp_resp.p,
+                       (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p);
+    if (d_desc)
+        hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx,
+                           (const uint8_t*)c->blur.p, (const vo_keypoint*)d_kps, (const int32_t*)d_counts, d_desc, cap);
     t_end(c, VO_T_DESCRIBE);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
