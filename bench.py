@@ -158,7 +158,7 @@ def main():
     ctx.set_timing(True)
     for _ in range(3):
         ctx.pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed, res.data_ptr())
-    ctx.sync()
+        ctx.sync()   # no overlap between calls here: every group is timed on an otherwise idle GPU
     kernel_ms = {name: ctx.kernel_time_ms(g)[0] for g, name in enumerate(capi.T_GROUPS)}
     alg_bytes = algorithmic_bytes(H, W, 2 * P, nfeat)
     dominant = max(alg_bytes, key=lambda g: kernel_ms[g])

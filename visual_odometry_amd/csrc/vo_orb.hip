@@ -507,7 +507,9 @@ __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* _
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_n, s_thr;
 
-    const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    // image index fastest: consecutive workgroups go to different XCDs, and with the level
+    // fastest one XCD would get every image's (largest) level-0 list
+    const int l = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
     constexpr int NT = 512;
     const LevelGeom& L = g.L[l];
     uint32_t total = min(cand_cnt[img * kLevels + l], (uint32_t)L.cand_cap);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* _
     __shared__ uint32_t srt[CAP];
     __shared__ uint32_t wsum[8];
     __shared__ uint32_t s_tot;
-    const int l = blockIdx.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.y, img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = 512;
     const LevelGeom& L = g.L[l];
     const int quota = L.quota;
@@ -1234,12 +1236,12 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     const int hbx = std::max((sel_need + 255) / 256, 1);
 #define VO_SELECT(CAPV)                                                                                              \
     do {                                                                                                             \
-        hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
+        hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
                            (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
                            (uint32_t*)c->flags.p);                                                                   \
         hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hbx * kLevels * N)), dim3(256), 0, s, g, CAPV, hbx, d_imgs, \
                            pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
-        hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(kLevels, N), dim3(512), 0, s, g,                              \
+        hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g,                              \
                            (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
                            (const float*)c->sel_resp.p, (uint16_t*)c->kp_x.p, (uint16_t*)c->kp_y.p,                  \
                            (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p);                     \
