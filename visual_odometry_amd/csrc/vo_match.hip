@@ -3,19 +3,20 @@
 // ratio loop of ref:src/feature_matcher.cpp:26-39.
 //
 // Integer VALU work, no MFMA: each lane keeps QPL query descriptors (8 dwords
-// each) in registers; 256-row train tiles are staged in LDS by coalesced 32-B
-// row loads and read back as wave-wide broadcasts; distance = 8 x
-// (v_xor, v_bcnt accumulate); the running two best are kept as packed keys
-// (distance << 16 | train row) so that one v_min and one v_med3 update them
-// and ties resolve to the lower train row exactly as an ascending scan with a
-// strict '<' does.
+// each) in registers; a train row is the same for every lane of a wavefront,
+// so it is fetched through the scalar cache into SGPRs and used as the scalar
+// operand of the xor; distance = 8 x (v_xor, v_bcnt accumulate); the running
+// two best are kept as packed keys (distance << 16 | train row) so that one
+// v_min and one v_med3 update them and ties resolve to the lower train row
+// exactly as an ascending scan with a strict '<' does.  The four wavefronts of
+// a workgroup take alternate 64-row runs of the train set and merge at the end.
 #include <cstdlib>
 
 #include "vo_internal.h"
 
 namespace vo {
 
-constexpr int MT_ROWS = 256;   // train rows per LDS tile (8 KiB)
+constexpr int MT_ROWS = 256;   // train rows per round of the four wavefronts (64 each)
 
 // One instruction each: the compiler otherwise turns the popcount chain into
 // v_bcnt(x, 0) + v_add3 trees and the median into max + min, 23 VALU instructions per
@@ -46,7 +47,6 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
                                                    int cnt_stride, int nq_max, size_t q_stride, const uint8_t* __restrict__ t,
                                                    const int32_t* __restrict__ nt_arr, int nt_max, size_t t_stride,
                                                    int32_t* __restrict__ idx2, int32_t* __restrict__ dist2) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[MT_ROWS * 8];
     __shared__ unsigned long long part[4][64 * QPL][2];
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,16 +79,10 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
 #pragma unroll
         for (int k = 0; k < QPL; ++k) thr[k] = 0xFFFFu;
         for (int t0 = 0; t0 < cn; t0 += MT_ROWS) {
-            __syncthreads();
-            if (t0 + tid < cn) {
-                const uint4* p = reinterpret_cast<const uint4*>(tb + (size_t)(cbase + t0 + tid) * 32);
-                uint4 a = p[0], c = p[1];
-                uint4* d = reinterpret_cast<uint4*>(&tile[tid * 8]);
-                d[0] = a;
-                d[1] = c;
-            }
-            __syncthreads();
-            const int r0 = wave * 64;
+            // A train row is the same for all 64 lanes: its address is wave-uniform, so the row
+            // comes through the scalar cache into SGPRs (s_load_dwordx8) and is an SGPR operand
+            // of the xor - no LDS staging, no workgroup barrier in the loop.
+            const int r0 = __builtin_amdgcn_readfirstlane(wave) * 64;
             const int rn = min(max(cn - t0 - r0, 0), 64);
             // distance of every query of this lane to one train row
             auto row_dist = [&](const uint4& ta, const uint4& tc, uint32_t* d) {
@@ -112,10 +106,10 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
                     k0[k] = min(k0[k], key);
                 }
             };
-            const uint4* tp = reinterpret_cast<const uint4*>(&tile[r0 * 8]);
+            const uint4* tp = reinterpret_cast<const uint4*>(tb + (size_t)(cbase + t0 + r0) * 32);
             const uint32_t jb = (uint32_t)(t0 + r0);
             int r = 0;
-            for (; r + 4 <= rn; r += 4) {   // four rows' broadcast reads in flight ahead of their use
+            for (; r + 4 <= rn; r += 4) {   // four rows (two s_load_dwordx16) per step
                 uint4 a0 = tp[2 * r], c0 = tp[2 * r + 1], a1 = tp[2 * r + 2], c1 = tp[2 * r + 3];
                 uint4 a2 = tp[2 * r + 4], c2 = tp[2 * r + 5], a3 = tp[2 * r + 6], c3 = tp[2 * r + 7];
                 uint32_t d0[QPL], d1[QPL], d2[QPL], d3[QPL];
@@ -239,10 +233,10 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
-    // Queries per lane.  One query per lane (59 VGPRs, 8 waves per SIMD) hides the two
-    // barriers of every train tile best and measures fastest on everything up to
-    // 65 536 x 65 536; more queries per lane only pay once the grid is so large that the
-    // train tiles' L2 re-reads (one pass per workgroup) start to matter.
+    // Queries per lane.  One query per lane (8 waves per SIMD) hides the scalar-load latency
+    // best and measures fastest on everything up to 65 536 x 65 536; more queries per lane only
+    // pay once the grid is so large that the train set's re-reads (one pass per workgroup)
+    // start to matter.
     int qpl = 4;
     while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
     if (const char* e = getenv("VO_KNN_QPL")) {   // tuning aid
