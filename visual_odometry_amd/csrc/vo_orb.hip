@@ -709,7 +709,10 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
     const bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
-    const bool interior = aligned && x0 >= 4 && x0 + BT_W + 4 <= L.w && y0 >= 3 && y0 + BT_H + 3 <= L.h;
+    // Every tile but a level's last column of tiles reads its source rows straight from global
+    // memory: rows beyond the top / bottom border are reflected per lane, and at the left border
+    // the four columns -4..-1 are the mirror image of columns 4..1 (one v_perm).
+    const bool direct = x0 + BT_W + 4 <= L.w;
 
     const uint32_t t0123 = (uint32_t)tabs.taps[0] | ((uint32_t)tabs.taps[1] << 8) | ((uint32_t)tabs.taps[2] << 16) |
                            ((uint32_t)tabs.taps[3] << 24);
@@ -734,14 +737,20 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
         *reinterpret_cast<uint4*>(&hs[rp * BT_W + 4 * gx]) = v;
     };
 
-    if (interior) {
+    if (direct) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
-            const uint8_t* p = base + (size_t)(y0 - 3 + 2 * rp) * pitch + (x0 - 4) + 4 * gx;
-            const uint32_t* pe = reinterpret_cast<const uint32_t*>(p);
-            const uint32_t* po = reinterpret_cast<const uint32_t*>(p + pitch);
-            uint32_t e0 = pe[0], e1 = pe[1], e2 = pe[2], o0 = po[0], o1 = po[1], o2 = po[2];
+            const bool left = x0 == 0 && gx == 0;   // window starts at column -4
+            const int c0 = left ? 0 : x0 - 4 + 4 * gx;
+            const uint8_t* pe = base + (uint32_t)(__mul24(reflect101(y0 - 3 + 2 * rp, L.h), pitch) + c0);
+            const uint8_t* po = base + (uint32_t)(__mul24(reflect101(y0 - 2 + 2 * rp, L.h), pitch) + c0);
+            uint32_t e0 = load_u32_unaligned(pe), e1 = load_u32_unaligned(pe + 4), e2 = load_u32_unaligned(pe + 8);
+            uint32_t o0 = load_u32_unaligned(po), o1 = load_u32_unaligned(po + 4), o2 = load_u32_unaligned(po + 8);
+            if (left) {   // loaded columns 0..11: shift right by one dword and mirror columns 4..1 in front
+                e2 = e1; e1 = e0; e0 = __builtin_amdgcn_perm(e2, e1, 0x01020304u);
+                o2 = o1; o1 = o0; o0 = __builtin_amdgcn_perm(o2, o1, 0x01020304u);
+            }
             uint32_t se[4], so[4];
             row4(e0, e1, e2, se);
             row4(o0, o1, o2, so);
