@@ -79,6 +79,11 @@ IMAGES = {
     "checker": lambda: synth.checkerboard(seed=9),
     "kitti": lambda: synth.frame_pair(8, height=376, width=1241)[0],
     "odd": lambda: synth.frame_pair(9, height=301, width=423)[1],
+    # one blur / FAST tile column only, widths that are not multiples of four, a level pyramid whose
+    # upper levels are smaller than the 31-px border
+    "narrow": lambda: synth.frame_pair(10, height=203, width=75)[0],
+    "low": lambda: synth.frame_pair(11, height=66, width=517)[1],
+    "edge68": lambda: synth.frame_pair(12, height=117, width=131)[0],
 }
 
 
@@ -104,7 +109,8 @@ def test_pyramid_blur_fast_stages(ctx, oracle, name):
 
 
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 1000), ("checker", 2000), ("checker", 100),
-                                        ("kitti", 4000), ("odd", 500), ("synth640", 37)])
+                                        ("kitti", 4000), ("odd", 500), ("synth640", 37), ("narrow", 300),
+                                        ("low", 300), ("edge68", 500)])
 def test_orb_detect_bit_exact(ctx, oracle, name, nfeat):
     img = IMAGES[name]()
     gk, gd = ctx.orb_detect(img, nfeat)
