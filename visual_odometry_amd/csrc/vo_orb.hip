@@ -191,6 +191,16 @@ __device__ __forceinline__ void ring_diffs(const uint8_t* p, int* d) {
     for (int k = 0; k < 16; ++k) d[k] = v - (int)p[off[k]];
 }
 
+// the 16 ring pixels themselves (same order); returns the centre
+__device__ __forceinline__ int ring_pixels(const uint8_t* p, int* r) {
+    constexpr int P = FP_W;
+    const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
+                         -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = (int)p[off[k]];
+    return (int)p[0];
+}
+
 // FAST-9/16 score of a pixel known to be a corner: max over 9-arcs of the arc's minimum
 // contrast (bright or dark), minus 1 - what cornerScore<16> returns.
 __device__ __forceinline__ int corner_score(const int* d) {
@@ -217,14 +227,45 @@ __device__ __forceinline__ int corner_score(const int* d) {
     return max(A, -B) - 1;
 }
 
+// The same score with both polarities in one ladder of packed 16-bit operations: every ring
+// pixel r becomes the pair (d, -d) = (256 - r, r) + (centre - 256, -centre), the first pair
+// being r * 0xFFFF + 256 (no borrow: 256 - r >= 1); the low half of the result is then the
+// largest arc minimum of d and the high half that of -d.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int corner_score_packed(const uint8_t* p) {
+    constexpr int P = FP_W;
+    const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
+                         -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
+    const int v = p[0];
+    const pk16 vc = {(short)(v - 256), (short)(-v)};
+    pk16 d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t rp = __umul24((uint32_t)p[off[k]], 0xFFFFu) + 256u;
+        d[k] = __builtin_bit_cast(pk16, rp) + vc;
+    }
+    pk16 m2[16], m4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2[i] = __builtin_elementwise_min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m4[i] = __builtin_elementwise_min(m2[i], m2[(i + 2) & 15]);
+    pk16 best = {-1000, -1000};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const pk16 m8 = __builtin_elementwise_min(m4[i], m4[(i + 4) & 15]);
+        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, d[(i + 8) & 15]));
+    }
+    return max((int)best.x, (int)best.y) - 1;
+}
+
 // Appends `val` for the lanes with pass == true to an LDS queue: one atomic per wavefront.
 __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, uint32_t* cnt, int lane) {
     unsigned long long m = __ballot(pass);
     if (m == 0) return;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(cnt, (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
-    if (pass) q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = val;
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (pass) q[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base))] = val;
 }
 
 // One launch over every level's 64x32 tiles of the 31-px interior.  Three filters of
@@ -329,13 +370,16 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             if (tot == 0) continue;   // wave-uniform
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&n1, tot);
-            qb = __shfl(qb, 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            // slot = wave-uniform base + number of passing lanes below this one (v_mbcnt pair)
+            auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
+                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
+            };
             const uint16_t pos = (uint16_t)(sy * (FT_W + 2) + 4 * gi - cx0);
-            if (T & (1u << 9)) q1[qb + (uint32_t)__popcll(m0 & below)] = pos;
-            if (T & (1u << 10)) q1[qb + c0 + (uint32_t)__popcll(m1 & below)] = (uint16_t)(pos + 1);
-            if (T & (1u << 25)) q1[qb + c0 + c1 + (uint32_t)__popcll(m2 & below)] = (uint16_t)(pos + 2);
-            if (T & (1u << 26)) q1[qb + c0 + c1 + c2 + (uint32_t)__popcll(m3 & below)] = (uint16_t)(pos + 3);
+            if (T & (1u << 9)) q1[slot(m0, qb)] = pos;
+            if (T & (1u << 10)) q1[slot(m1, qb + c0)] = (uint16_t)(pos + 1);
+            if (T & (1u << 25)) q1[slot(m2, qb + c0 + c1)] = (uint16_t)(pos + 2);
+            if (T & (1u << 26)) q1[slot(m3, qb + c0 + c1 + c2)] = (uint16_t)(pos + 3);
         }
     }
     __syncthreads();
@@ -349,15 +393,17 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         if (i < c1) {
             pos = q1[i];
             int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
-            int d[16];
-            ring_diffs(&px[(sy + 3) * FP_W + cx0 + sx], d);
-            // ring masks through the sign bit: mask = (mask << 1) | sign(thr - d) is one
-            // v_alignbit per ring pixel (the reversed bit order keeps arcs contiguous)
+            int r[16];
+            const int v = ring_pixels(&px[(sy + 3) * FP_W + cx0 + sx], r);
+            // ring masks through the sign bit: mask = (mask << 1) | sign(thr -+ (centre - ring))
+            // is one add and one v_alignbit per ring pixel and polarity (the reversed bit order
+            // keeps arcs contiguous)
+            const int kb = kFastThr - v, kd = kFastThr + v;
             unsigned bright = 0, dark = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(kFastThr - d[k]), 31);
-                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(kFastThr + d[k]), 31);
+                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(kb + r[k]), 31);
+                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(kd - r[k]), 31);
             }
             pass = has_arc9(bright & 0xFFFFu) || has_arc9(dark & 0xFFFFu);
         }
@@ -370,9 +416,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     for (uint32_t i = tid; i < c2; i += 256) {
         uint16_t pos = q2[i];
         int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
-        int d[16];
-        ring_diffs(&px[(sy + 3) * FP_W + cx0 + sx], d);
-        sc[sy * FS_W + sx] = (uint8_t)corner_score(d);
+        sc[sy * FS_W + sx] = (uint8_t)corner_score_packed(&px[(sy + 3) * FP_W + cx0 + sx]);
     }
     __syncthreads();
 
