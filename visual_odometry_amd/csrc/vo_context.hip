@@ -17,6 +17,7 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p) {
         VO_HIP(c, hipStreamSynchronize(c->stream));
         if (c->side) VO_HIP(c, hipStreamSynchronize(c->side));
+        if (c->aux) VO_HIP(c, hipStreamSynchronize(c->aux));
         VO_HIP(c, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -40,13 +41,15 @@ static hipEvent_t take_event(vo_ctx* c) {
     return c->ev_pool[c->ev_used++];
 }
 
-void t_begin(vo_ctx* c, int group) {
+void t_begin_on(vo_ctx* c, int group, hipStream_t s) {
     if (!((c->timing >> group) & 1u) || c->ev_used > 60000) return;
     hipEvent_t a = take_event(c), b = take_event(c);
     if (!a || !b) return;
     c->ev_pairs[group].emplace_back(a, b);
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, s);
 }
+
+void t_begin(vo_ctx* c, int group) { t_begin_on(c, group, c->stream); }
 
 void t_end_on(vo_ctx* c, int group, hipStream_t s) {
     if (!((c->timing >> group) & 1u) || c->ev_pairs[group].empty()) return;
@@ -80,7 +83,10 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_rdone, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_rdone, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
@@ -93,6 +99,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
                       &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->m_top2,   &c->m_qidx,
@@ -105,7 +112,10 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_rdone) (void)hipEventDestroy(c->ev_rdone);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -118,6 +128,7 @@ extern "C" int vo_sync(vo_ctx* c) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
     VO_HIP(c, hipStreamSynchronize(c->side));
+    VO_HIP(c, hipStreamSynchronize(c->aux));
     c->side_busy = false;
     return VO_OK;
 }
@@ -126,6 +137,7 @@ extern "C" int vo_set_timing(vo_ctx* c, int groups) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
     VO_HIP(c, hipStreamSynchronize(c->side));
+    VO_HIP(c, hipStreamSynchronize(c->aux));
     c->timing = (unsigned)groups & (unsigned)VO_T_ALL;
     for (auto& v : c->ev_pairs) v.clear();
     c->ev_used = 0;
@@ -135,7 +147,9 @@ extern "C" int vo_set_timing(vo_ctx* c, int groups) {
 extern "C" float vo_kernel_time_ms(vo_ctx* c, int group, int* launches) {
     if (launches) *launches = 0;
     if (!c || group < 0 || group >= VO_T_COUNT) return -1.f;
-    if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->side) != hipSuccess) return -1.f;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->side) != hipSuccess ||
+        hipStreamSynchronize(c->aux) != hipSuccess)
+        return -1.f;
     double sum = 0;
     int n = 0;
     for (auto& pr : c->ev_pairs[group]) {

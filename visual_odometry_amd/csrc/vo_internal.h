@@ -66,6 +66,11 @@ struct vo_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_init = nullptr, ev_rdone = nullptr;
     bool side_busy = false;
+    // FAST on level 0 needs only the input images: it runs on a third stream beside the resize
+    // chain that builds the other levels (ev_fork orders it after the counter reset, ev_fast0
+    // orders candidate selection after it).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fast0 = nullptr;
     std::string err;
     unsigned timing = 0;   // bit g: kernel group g is bracketed by events
     std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)
@@ -93,7 +98,8 @@ int fail(vo_ctx* c, int code, const std::string& msg);
 // Records the begin / end event of one launch of kernel group `group` (no-ops unless timing is on).
 void t_begin(vo_ctx* c, int group);
 void t_end(vo_ctx* c, int group);
-void t_end_on(vo_ctx* c, int group, hipStream_t s);   // end event on another stream of the context
+void t_begin_on(vo_ctx* c, int group, hipStream_t s);
+void t_end_on(vo_ctx* c, int group, hipStream_t s);   // events on another stream of the context
 // Makes the main stream wait for work still running on the side stream.
 int join_side(vo_ctx* c);
 int ensure(vo_ctx* c, DevBuf& b, size_t bytes);

@@ -277,6 +277,7 @@ __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, 
 // then 3x3 non-max suppression, the border filter and one global atomic per tile.
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
+                                                   uint32_t tile_first, uint32_t ntiles, uint32_t tile_magic,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
     __shared__ __attribute__((aligned(16))) uint8_t px[FP_H * FP_W];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
@@ -285,9 +286,10 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     __shared__ uint32_t n1, n2, nlist, gbase;
 
     uint32_t work;
-    if (!xcd_remap((uint32_t)g.fast_tiles * (uint32_t)g.n_images, &work)) return;
+    if (!xcd_remap(ntiles * (uint32_t)g.n_images, &work)) return;
     int img, tile;
-    split_work(work, (uint32_t)g.fast_tiles, g.fast_magic, &img, &tile);
+    split_work(work, ntiles, tile_magic, &img, &tile);
+    tile += (int)tile_first;   // this launch covers tiles [tile_first, tile_first + ntiles) of every image
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t te = tab[g.fast_ttab + tile];
     const int l = (int)(te >> 24);
@@ -1268,6 +1270,27 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     const uint8_t* pyr = (const uint8_t*)c->pyr.p;
     VO_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, (size_t)N * kLevels * 4, s));
     VO_HIP(c, hipMemsetAsync(c->flags.p, 0, 256, s));
+    // level 0 (needs only the input) and the other levels are separate FAST launches
+    const uint32_t tiles0 = (uint32_t)(kLevels > 1 ? g.L[1].fast_tile0 : g.fast_tiles);
+    const uint32_t tiles_up = (uint32_t)g.fast_tiles - tiles0;
+    auto launch_fast = [&](hipStream_t fs, uint32_t first, uint32_t count) {
+        const uint32_t magic = (uint32_t)std::min<unsigned long long>(0x100000000ull / count, 0xFFFFFFFFull);
+        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(count * (uint32_t)N)), dim3(256), 0, fs, g, d_imgs, pyr,
+                           (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p, (uint32_t*)c->cand_cnt.p);
+    };
+    // The resize chain is seven dependent, bandwidth- and latency-bound launches that leave the
+    // vector ALUs mostly idle, FAST is bound by them: level 0's FAST runs beside the chain on the
+    // auxiliary stream.  With event brackets on the resize group everything stays on one stream,
+    // so that the group's time is that of its kernels alone.
+    const bool fast0_aside = tiles0 > 0 && !((c->timing >> VO_T_RESIZE) & 1u);
+    if (fast0_aside) {
+        VO_HIP(c, hipEventRecord(c->ev_fork, s));
+        VO_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        t_begin_on(c, VO_T_FAST, c->aux);
+        launch_fast(c->aux, 0, tiles0);
+        t_end_on(c, VO_T_FAST, c->aux);
+        VO_HIP(c, hipEventRecord(c->ev_fast0, c->aux));
+    }
     t_begin(c, VO_T_RESIZE);
     for (int l = 1; l < kLevels; ++l) {
         uint32_t items = g.L[l].ncg * (uint32_t)((g.L[l].h + RS_ROWS - 1) / RS_ROWS);
@@ -1276,13 +1299,17 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
                            (const uint32_t*)c->tab.p);
     }
     t_end(c, VO_T_RESIZE);
-    if (g.fast_tiles > 0) {
+    if (tiles0 > 0 && !fast0_aside) {
         t_begin(c, VO_T_FAST);
-        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid((uint32_t)g.fast_tiles * N)), dim3(256), 0, s, g, d_imgs, pyr,
-                           (const uint32_t*)c->tab.p, (uint32_t*)c->cand.p,
-                           (uint32_t*)c->cand_cnt.p);
+        launch_fast(s, 0, tiles0);
         t_end(c, VO_T_FAST);
     }
+    if (tiles_up > 0) {
+        t_begin(c, VO_T_FAST);
+        launch_fast(s, tiles0, tiles_up);
+        t_end(c, VO_T_FAST);
+    }
+    if (fast0_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_fast0, 0));
     t_begin(c, VO_T_SELECT);
     int sel_need = 0;   // upper bound of a level's list after the first cut, for the Harris grid
     for (int l = 0; l < kLevels; ++l) sel_need = std::max(sel_need, std::min(g.sel_cap, g.L[l].cand_cap));
