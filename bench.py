@@ -65,6 +65,25 @@ def measured_traffic(workload, pairs, group):
     return rec.get("bytes_per_launch", {}).get(group)
 
 
+def measured_valu(workload, pairs, kernel, launch_ms):
+    """Vector-ALU issue accounting of a kernel from the committed SQ counter passes: wavefront VALU
+    instructions per launch and the share of the GPU's issue slots they fill over the launch
+    duration measured in this run (a wave64 instruction holds one of 1024 SIMDs for four cycles
+    at 2.4 GHz; plain adds and logic ops in long runs issue faster, so the share is an upper
+    bound of the occupancy and a kernel at ~0.9 is issue-bound)."""
+    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    k = rec.get("kernels", {}).get(kernel)
+    if rec.get("workload") != workload or rec.get("pairs_per_step") != pairs or not k or "SQ_INSTS_VALU" not in k:
+        return None
+    slots = rec["simds"] * rec["clock_ghz"] * 1e9 * launch_ms * 1e-3 / 4.0
+    return {"wave_insts_per_launch": k["SQ_INSTS_VALU"], "issue_slots_per_launch": slots,
+            "frac": k["SQ_INSTS_VALU"] / slots}
+
+
 def cpu_baseline(frames, K, max_features, fixed_iters, budget_s=12.0):
     """The CPU oracle (scalar port of the reference path) on the same frames, one thread."""
     from oracle import oracle as O
@@ -206,13 +225,17 @@ def main():
         "roofline": {"bound": "hbm", "kernel": KERNEL_OF_GROUP[dominant], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(args.workload, P, dominant),
+                     "valu": measured_valu(args.workload, P, KERNEL_OF_GROUP[dominant], dom_avg_ms),
                      "avg_launch_ms": dom_avg_ms, "launches_timed": dom_launches,
                      "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": dom_bytes,
                      "note": "achieved = algorithmic bytes per launch / mean launch duration by HIP events on the "
                              "kernel's stream inside the timed steps (with more than one stream the duration "
                              "includes what the neighbour stream's kernels take from the GPU); traffic = "
-                             "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the configuration matches"},
+                             "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the configuration matches; "
+                             "valu = the kernel's wavefront VALU instructions per launch (SQ_INSTS_VALU, "
+                             "profiles/) against the vector-ALU issue slots of the launch: the ceiling that "
+                             "binds this kernel, the HBM fraction being what the contract asks for"},
         "pipeline": {"mean_keypoints": float(np.mean(out["n_kp1"])), "mean_matches": float(np.mean(out["n_matches"])),
                      "mean_inliers": float(np.mean(out["inliers"])), "valid_fraction": float(np.mean(out["valid"])),
                      "mean_ransac_iters": float(np.mean(out["ransac_iters"])),
@@ -221,27 +244,31 @@ def main():
     }
 
     if not args.no_sequence:
-        # the same pipeline fed as a video sequence: P + 1 consecutive frames -> P pairs, each frame
-        # detected once (what a streaming caller of the reference's main loop would use)
+        # the same pipeline fed as a video sequence: 2P consecutive frames -> 2P - 1 pairs, each
+        # frame detected once (what a streaming caller of the reference's main loop would use).
+        # 2P frames, so that the detection launches have the size of the headline steps' and the
+        # per-kernel averages of a profile of this command are not mixed from two launch sizes.
         # (synthetic sequence: the two frames of the first pair alternate, so that every
         # consecutive pair shows the same scene under a small motion)
-        seq = torch.from_numpy(np.stack([frames[i & 1] for i in range(P + 1)])).cuda()
-        res_seq = torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        F = 2 * P
+        seq = torch.from_numpy(np.stack([frames[i & 1] for i in range(F)])).cuda()
+        res_seq = torch.zeros((F - 1) * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
         reps = max(3, args.steps // 4)
         for _ in range(2):
-            ctx.pipeline_sequence_dev(seq.data_ptr(), P + 1, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+            ctx.pipeline_sequence_dev(seq.data_ptr(), F, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
                                       res_seq.data_ptr())
         fence()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ctx.pipeline_sequence_dev(seq.data_ptr(), P + 1, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+            ctx.pipeline_sequence_dev(seq.data_ptr(), F, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
                                       res_seq.data_ptr())
         fence()
         sd = (time.perf_counter() - t0) / reps
         t = torch.tensor([sd], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        line["sequence_mode"] = {"frames_per_step_per_gpu": P + 1, "value": P * world / float(t.item()),
+        line["sequence_mode"] = {"frames_per_step_per_gpu": F, "pairs_per_step_per_gpu": F - 1,
+                                 "value": (F - 1) * world / float(t.item()),
                                  "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
                                  "note": "consecutive frames, every frame detected once (vo_pipeline_sequence_dev); "
                                          "not the headline metric, which detects both images of every pair"}

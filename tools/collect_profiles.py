@@ -39,12 +39,13 @@ fe = per_kernel(latest("gpurun_out/pmc_traffic/bench_FETCH_SIZE/**/*counter_coll
 wr = per_kernel(latest("gpurun_out/pmc_traffic/bench_WRITE_SIZE/**/*counter_collection.csv"))
 cf = per_kernel(latest("gpurun_out/pmc_traffic/calib_FETCH_SIZE/**/*counter_collection.csv"))
 cw = per_kernel(latest("gpurun_out/pmc_traffic/calib_WRITE_SIZE/**/*counter_collection.csv"))
+# FAST: two launches per step (level 0, upper levels); the figure is that of an average launch
 groups = {"fast": ("fast_kernel", 1), "blur": ("blur_kernel", 1), "describe": ("describe_kernel", 1),
           "resize": ("resize_kernel", 7)}   # seven resize launches per step
 out = {
     "workload": "c2_640x480_2000kp", "pairs_per_step": 256,
     "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-              "bench.py --steps 3 --warmup 1 --streams 1; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  Calibration "
+              "bench.py --steps 3 --warmup 1 --streams 1 --no-sequence; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  Calibration "
               f"(tools/calib_fetch, same passes): a 1 GiB read reports FETCH_SIZE {cf['read_dword']:.0f} KiB with dword "
               f"loads and {cf['read_dwordx4']:.0f} KiB with dwordx4 loads (half the bytes), a 256 MiB dword write "
               f"reports WRITE_SIZE {cw['write_dword']:.0f} KiB (exact).",
@@ -53,3 +54,15 @@ out = {
 }
 json.dump(out, open(os.path.join(R, "profiles/pmc_traffic.json"), "w"), indent=1)
 print(out["bytes_per_launch"])
+
+# instruction-mix counters per launch (tools/pmc_sq.sh passes), when they were taken
+if glob.glob(os.path.join(R, "gpurun_out/pmc_sq/a/**/*counter_collection.csv"), recursive=True):
+    import subprocess
+    js = subprocess.run([sys.executable, os.path.join(R, "tools/pmc_sq_json.py"), os.path.join(R, "gpurun_out/pmc_sq/a"),
+                         os.path.join(R, "gpurun_out/pmc_sq/b")], check=True, capture_output=True, text=True).stdout
+    open(os.path.join(R, "profiles/pmc_sq.json"), "w").write(js)
+    k = json.loads(js)["kernels"]
+    for name in ("fast_kernel", "blur_kernel", "describe_kernel", "orient_kernel", "knn2_kernel", "resize_kernel"):
+        if name in k:
+            print("  ", name.ljust(18), "VALU wave insts/launch %.3g" % k[name].get("SQ_INSTS_VALU", float("nan")),
+                  "issue frac %.2f" % k[name].get("valu_issue_frac", float("nan")))

@@ -4,9 +4,9 @@
     python tools/pmc_sq_json.py gpurun_out/pmc_sq/a gpurun_out/pmc_sq/b > profiles/pmc_sq.json
 
 Reads the newest rocprofv3 counter_collection.csv of each pass directory (tools/pmc_sq.sh
-writes them), keeps for every kernel the dispatches with its largest grid (the full batches of
-bench.py; the sequence-mode and single-image launches are smaller) and averages every counter
-and the dispatch duration over them.  `valu_issue_frac` is the share of the GPU's vector-ALU
+writes them; its bench.py command launches full batches only) and averages every counter and
+the dispatch duration over all dispatches of a kernel - an average launch, as in bench.py's
+roofline (FAST has two launches per step, level 0 and the upper levels; resize seven).  `valu_issue_frac` is the share of the GPU's vector-ALU
 issue slots the kernel's wavefront instructions fill while it runs: one wave64 VALU instruction
 occupies a SIMD for four cycles, 256 CUs x 4 SIMDs, clock from the agent's max (2400 MHz).
 """
@@ -36,20 +36,19 @@ out = {}
 for name, disp in per.items():
     if not name.endswith("_kernel"):
         continue
-    top = max(meta[k][0] for k in disp)
-    keys = [k for k in disp if meta[k][0] == top]
+    keys = list(disp)
     acc = collections.defaultdict(list)
     for k in keys:
         for c, v in disp[k].items():
             acc[c].append(v)
     row = {c: sum(v) / len(v) for c, v in acc.items()}
-    row["grid_size"] = top
+    row["grid_size_max"] = max(meta[k][0] for k in keys)
     row["launches"] = len({k[1] for k in keys if k[0] == sys.argv[1]}) or len(keys)
     row["duration_ns"] = sum(meta[k][1] for k in keys) / len(keys)
     if "SQ_INSTS_VALU" in row:
         row["valu_issue_frac"] = row["SQ_INSTS_VALU"] * 4.0 / (SIMDS * row["duration_ns"] * CLOCK_GHZ)
     out[name] = row
-print(json.dumps({"source": "tools/pmc_sq.sh (two rocprofv3 --pmc passes over bench.py --steps 3 --warmup 1 "
-                            "--no-hamming --no-cpu-baseline), averaged by tools/pmc_sq_json.py over each "
-                            "kernel's largest-grid dispatches; durations are those under counter collection",
+print(json.dumps({"workload": "c2_640x480_2000kp", "pairs_per_step": 256, "source": "tools/pmc_sq.sh (two rocprofv3 --pmc passes over bench.py --steps 3 --warmup 1 "
+                            "--no-hamming --no-cpu-baseline --no-sequence), averaged by tools/pmc_sq_json.py over all "
+                            "dispatches of a kernel; durations are those under counter collection",
                   "clock_ghz": CLOCK_GHZ, "simds": SIMDS, "kernels": out}, indent=1))

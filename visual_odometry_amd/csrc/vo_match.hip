@@ -2,14 +2,17 @@
 // gfx950.  Stands in for cv::BFMatcher(NORM_HAMMING)::knnMatch(k=2) and the
 // ratio loop of ref:src/feature_matcher.cpp:26-39.
 //
-// Integer VALU work, no MFMA: each lane keeps QPL query descriptors (8 dwords
-// each) in registers; a train row is the same for every lane of a wavefront,
-// so it is fetched through the scalar cache into SGPRs and used as the scalar
-// operand of the xor; distance = 8 x (v_xor, v_bcnt accumulate); the running
-// two best are kept as packed keys (distance << 16 | train row) so that one
-// v_min and one v_med3 update them and ties resolve to the lower train row
-// exactly as an ascending scan with a strict '<' does.  The four wavefronts of
-// a workgroup take alternate 64-row runs of the train set and merge at the end.
+// Integer VALU work, no MFMA: each lane keeps its query descriptor(s) (8 dwords
+// each) in registers; a train row is the same for every lane of a wavefront;
+// distance = 8 x (v_xor, v_bcnt accumulate); the running two best are kept as
+// packed keys (distance << 16 | train row) so that one v_min and one v_med3
+// update them and ties resolve to the lower train row exactly as an ascending
+// scan with a strict '<' does.  The wavefronts of a workgroup take alternate
+// 64-row runs of the train set and merge at the end.  Two kernels differ in how
+// the train row reaches the xor: knn2_bcast_kernel (one query per lane, the
+// default) broadcasts it from wavefront-private LDS into vector registers,
+// knn2_kernel<QPL> (several queries per lane, very large batches) fetches it
+// through the scalar cache and uses it as the scalar operand.
 #include <cstdlib>
 
 #include "vo_internal.h"
@@ -172,6 +175,136 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
     }
 }
 
+// The same search with the train rows in vector registers.  A v_xor with an SGPR operand
+// issues at the slow rate (about 4.2 cycles per wave64 instruction on gfx950, like v_bcnt),
+// one between vector registers in a run of its kind at about 2.6: each wavefront copies its
+// 64-row block into a private 2 KB LDS region (one coalesced row per lane) and reads the rows
+// back with uniform-address ds_read_b128 (broadcast, about 4.5 cycles per instruction and CU);
+// the 32 xors of four rows are issued as one run ahead of the popcount chains.  The LDS region
+// is private to the wavefront and LDS operations of one wavefront execute in order, so the
+// loop needs no workgroup barrier; the next block's global loads are in flight during the
+// current block's arithmetic.
+template <int NW>   // wavefronts per workgroup: they split the train rows and merge at the end
+__global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr,
+                                                         int cnt_stride, int nq_max, size_t q_stride,
+                                                         const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr,
+                                                         int nt_max, size_t t_stride, int32_t* __restrict__ idx2,
+                                                         int32_t* __restrict__ dist2) {
+    __shared__ uint4 rows[NW][128];   // per wavefront: 64 rows of two uint4
+    __shared__ unsigned long long part[NW][64][2];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
+    const int nt = nt_arr ? min(nt_arr[b * cnt_stride], nt_max) : nt_max;
+    const int qbase = blockIdx.x * 64;
+    if (qbase >= nq) return;
+    const uint8_t* qb = q + (size_t)b * q_stride;
+    const uint8_t* tb = t + (size_t)b * t_stride;
+
+    uint32_t qr[8];
+    {
+        const int qi = min(qbase + lane, nq - 1);
+        const uint4* p = reinterpret_cast<const uint4*>(qb + (size_t)qi * 32);
+        const uint4 a = p[0], c = p[1];
+        qr[0] = a.x; qr[1] = a.y; qr[2] = a.z; qr[3] = a.w;
+        qr[4] = c.x; qr[5] = c.y; qr[6] = c.z; qr[7] = c.w;
+    }
+    unsigned long long best0 = ~0ull, best1 = ~0ull;
+    uint4* my_rows = rows[wave];
+
+    for (int cbase = 0; cbase < nt; cbase += 65536) {
+        const int cn = min(nt - cbase, 65536);
+        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, thr = 0xFFFFu;
+        const uint4* tcb = reinterpret_cast<const uint4*>(tb + (size_t)cbase * 32);
+        auto fetch = [&](int first, uint4* a, uint4* c) {   // row first + lane of the chunk (clamped)
+            const int row = min(first + lane, cn - 1);
+            *a = tcb[2 * row];
+            *c = tcb[2 * row + 1];
+        };
+        auto update = [&](uint32_t d, uint32_t j) {
+            const uint32_t key = (d << 16) | j;
+            k1 = med3u(k0, k1, key);
+            k0 = min(k0, key);
+        };
+        uint4 na, nc;
+        int first = wave * 64;   // this wavefront takes every NW-th 64-row block
+        if (first < cn) fetch(first, &na, &nc);
+        for (; first < cn; first += 64 * NW) {
+            my_rows[2 * lane] = na;
+            my_rows[2 * lane + 1] = nc;
+            if (first + 64 * NW < cn) fetch(first + 64 * NW, &na, &nc);
+            const int rn = min(cn - first, 64);
+            int r = 0;
+            for (; r + 4 <= rn; r += 4) {
+                uint32_t x[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 ra = my_rows[2 * (r + i)], rc = my_rows[2 * (r + i) + 1];
+                    x[i][0] = ra.x; x[i][1] = ra.y; x[i][2] = ra.z; x[i][3] = ra.w;
+                    x[i][4] = rc.x; x[i][5] = rc.y; x[i][6] = rc.z; x[i][7] = rc.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[i][k] ^= qr[k];
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t v = bcnt_acc(x[i][0], 0u);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) v = bcnt_acc(x[i][k], v);
+                    d[i] = v;
+                }
+                const bool better = (d[0] < thr) | (d[1] < thr) | (d[2] < thr) | (d[3] < thr);
+                if (__any(better)) {
+                    const uint32_t j = (uint32_t)(first + r);
+                    update(d[0], j);
+                    update(d[1], j + 1);
+                    update(d[2], j + 2);
+                    update(d[3], j + 3);
+                    thr = k1 >> 16;
+                }
+            }
+            for (; r < rn; ++r) {
+                const uint4 ra = my_rows[2 * r], rc = my_rows[2 * r + 1];
+                uint32_t v = bcnt_acc(qr[0] ^ ra.x, 0u);
+                v = bcnt_acc(qr[1] ^ ra.y, v);
+                v = bcnt_acc(qr[2] ^ ra.z, v);
+                v = bcnt_acc(qr[3] ^ ra.w, v);
+                v = bcnt_acc(qr[4] ^ rc.x, v);
+                v = bcnt_acc(qr[5] ^ rc.y, v);
+                v = bcnt_acc(qr[6] ^ rc.z, v);
+                v = bcnt_acc(qr[7] ^ rc.w, v);
+                update(v, (uint32_t)(first + r));
+            }
+            thr = k1 >> 16;
+        }
+        const unsigned long long b0 =
+            k0 == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(k0 >> 16) << 32) | (uint32_t)(cbase + (k0 & 0xFFFF));
+        const unsigned long long b1 =
+            k1 == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(k1 >> 16) << 32) | (uint32_t)(cbase + (k1 & 0xFFFF));
+        merge2(best0, best1, b0, b1);
+    }
+    part[wave][lane][0] = best0;
+    part[wave][lane][1] = best1;
+    __syncthreads();
+    if (tid < 64) {
+        const int qi = qbase + tid;
+        if (qi < nq) {
+            unsigned long long a0 = part[0][tid][0], a1 = part[0][tid][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) merge2(a0, a1, part[w][tid][0], part[w][tid][1]);
+            const size_t o = ((size_t)b * nq_max + qi) * 2;
+            idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
+            idx2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(uint32_t)a1;
+            dist2[o] = a0 == ~0ull ? -1 : (int32_t)(a0 >> 32);
+            dist2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(a1 >> 32);
+        }
+    }
+}
+
 // Lowe ratio test and ordered compaction (query order), one workgroup per
 // pair.  Also gathers the matched keypoint coordinates.
 __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ idx2, const int32_t* __restrict__ dist2,
@@ -233,10 +366,9 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
-    // Queries per lane.  One query per lane (8 waves per SIMD) hides the scalar-load latency
-    // best and measures fastest on everything up to 65 536 x 65 536; more queries per lane only
-    // pay once the grid is so large that the train set's re-reads (one pass per workgroup)
-    // start to matter.
+    // Queries per lane.  One query per lane measures fastest on everything up to
+    // 65 536 x 65 536; more queries per lane only pay once the grid is so large that the train
+    // set's re-reads (one pass per workgroup) start to matter.
     int qpl = 4;
     while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
     if (const char* e = getenv("VO_KNN_QPL")) {   // tuning aid
@@ -246,7 +378,26 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
     hipStream_t s = c->stream;
     t_begin(c, VO_T_KNN2);
-    if (qpl == 4)
+    // One query per lane: the variant with the train rows in vector registers.  VO_KNN_MODE=0
+    // selects the scalar-operand kernel instead, 4 / 8 / 16 a workgroup size (tuning aids).
+    const char* mode_env = getenv("VO_KNN_MODE");
+    const int mode = mode_env ? atoi(mode_env) : 1;
+    if (qpl == 1 && mode >= 1) {
+        // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
+        // still has several to switch between
+        const long long wgs = (long long)grid.x * grid.y;
+        int nw = wgs * 4 >= 8 * 1024 ? 4 : wgs * 8 >= 8 * 1024 ? 8 : 16;
+        if (mode == 4 || mode == 8 || mode == 16) nw = mode;
+        if (nw == 4)
+            hipLaunchKernelGGL(knn2_bcast_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
+                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
+        else if (nw == 8)
+            hipLaunchKernelGGL(knn2_bcast_kernel<8>, grid, dim3(512), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
+                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
+        else
+            hipLaunchKernelGGL(knn2_bcast_kernel<16>, grid, dim3(1024), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
+                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
+    } else if (qpl == 4)
         hipLaunchKernelGGL(knn2_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);
     else if (qpl == 2)
