@@ -458,18 +458,18 @@ __device__ __forceinline__ uint32_t f2sortable(float f) {
 }
 
 // HarrisResponses: 7x7 block of Sobel-like gradients around (x0, y0), int32 sums, float32
-// response in OpenCV's operation order.  The 9x9 support is fetched as 9 rows of three
-// unaligned dwords and walked with a three-row register window.
+// response in OpenCV's operation order.  The 9x9 support is fetched as 9 rows of twelve
+// unaligned bytes and walked with a three-row register window.
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x0, int y0) {
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
     uint32_t w[9][3];
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
+        // one 12-byte load per row: the lanes' windows are scattered, so every load instruction
+        // costs a cache-line look-up per lane whatever its width
         const uint8_t* p = img + (size_t)(y0 - 4 + r) * pitch + (x0 - 4);
-        w[r][0] = load_u32_unaligned(p);
-        w[r][1] = load_u32_unaligned(p + 4);
-        w[r][2] = load_u32_unaligned(p + 8);
+        __builtin_memcpy(w[r], p, 12);
     }
     auto px = [&](int r, int c) -> int { return (int)((w[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
     int a = 0, b = 0, c = 0;
