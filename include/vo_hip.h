@@ -60,18 +60,25 @@ int vo_ctx_create(int device, vo_ctx** out);
 void vo_ctx_destroy(vo_ctx* ctx);
 /* Message of the last failing call on this context ("" if none). */
 const char* vo_last_error(const vo_ctx* ctx);
-/* hipStream_t the context enqueues on (as void*); vo_pipeline_pairs_dev also
- * uses a second, internal stream - see there. */
+/* hipStream_t the context enqueues on (as void*).  Detection forks part of its
+ * work (FAST on level 0) to an internal auxiliary stream and joins it again
+ * before candidate selection, so work enqueued on this stream after a
+ * detection call is ordered after all of it.  vo_pipeline_*_dev also use a
+ * second internal stream that is NOT joined - see there. */
 void* vo_ctx_stream(vo_ctx* ctx);
 int vo_sync(vo_ctx* ctx);
-/* Kernel timing with HIP events recorded on the context's stream.
+/* Kernel timing with HIP events recorded on the stream a kernel group runs on.
  * vo_set_timing(ctx, groups) takes a bit mask (1 << VO_T_*, VO_T_ALL for every
  * group, 0 to switch timing off): every launch of a selected kernel group is
  * then bracketed by a fresh event pair.  Nothing waits on the events, but each
  * bracket costs about 10 us of stream time, so select only what is needed
  * inside a throughput measurement.  vo_kernel_time_ms() waits for the stream,
  * then returns the mean duration in milliseconds over the launches recorded
- * since the last vo_set_timing() and their number in *launches; -1 if none.
+ * since the last vo_set_timing() and their number in *launches; -1 if none
+ * (FAST has two launches per detection call: level 0 and the upper levels).
+ * While the resize group is selected, detection keeps all its kernels on one
+ * stream, so that a group's time is that of its kernels alone; otherwise the
+ * level-0 FAST launch shares the GPU with the resize chain.
  * Groups: */
 enum {
     VO_T_RESIZE = 0,   /* the seven pyramid resize launches of one detect call */
@@ -155,7 +162,8 @@ int vo_find_essential(vo_ctx* ctx, const float* p1, const float* p2, int n, cons
  * d_results: n_pairs records in device memory.  The call only enqueues: the
  * RANSAC rounds run on a second stream of the context so that the next call's
  * detection overlaps them, and d_results is complete after vo_sync() (which
- * waits for both streams; waiting on vo_ctx_stream() alone is not enough). */
+ * waits for every stream of the context; waiting on vo_ctx_stream() alone is
+ * not enough). */
 int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
                           size_t image_stride, int max_features, float ratio, const double K[4],
                           double threshold, double confidence, int fixed_iters,
