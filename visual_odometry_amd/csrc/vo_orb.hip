@@ -407,7 +407,11 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 bright = __builtin_amdgcn_alignbit(bright, (unsigned)(kb + r[k]), 31);
                 dark = __builtin_amdgcn_alignbit(dark, (unsigned)(kd - r[k]), 31);
             }
-            pass = has_arc9(bright & 0xFFFFu) || has_arc9(dark & 0xFFFFu);
+            // a ring pixel is in at most one of the masks, so only the one with nine or more
+            // bits can hold an arc: one arc test instead of two
+            bright &= 0xFFFFu;
+            dark &= 0xFFFFu;
+            pass = has_arc9(__popc(bright) >= 9 ? bright : dark);
         }
         wave_push(pass, pos, q2, &n2, lane);
     }
