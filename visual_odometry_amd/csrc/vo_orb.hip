@@ -791,15 +791,30 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
-            const bool left = x0 == 0 && gx == 0;   // window starts at column -4
-            const int c0 = left ? 0 : x0 - 4 + 4 * gx;
-            const uint8_t* pe = base + (uint32_t)(__mul24(reflect101(y0 - 3 + 2 * rp, L.h), pitch) + c0);
-            const uint8_t* po = base + (uint32_t)(__mul24(reflect101(y0 - 2 + 2 * rp, L.h), pitch) + c0);
-            uint32_t e0 = load_u32_unaligned(pe), e1 = load_u32_unaligned(pe + 4), e2 = load_u32_unaligned(pe + 8);
-            uint32_t o0 = load_u32_unaligned(po), o1 = load_u32_unaligned(po + 4), o2 = load_u32_unaligned(po + 8);
-            if (left) {   // loaded columns 0..11: shift right by one dword and mirror columns 4..1 in front
-                e2 = e1; e1 = e0; e0 = __builtin_amdgcn_perm(e2, e1, 0x01020304u);
-                o2 = o1; o1 = o0; o0 = __builtin_amdgcn_perm(o2, o1, 0x01020304u);
+            // A lane loads only its own dword of each row (columns x0 + 4*gx ..); the dwords left
+            // and right of it are its neighbours' (DPP row shifts inside the 16 lanes of a tile
+            // row), and the two lanes at the ends of the row fetch the halo dword instead: a third
+            // of the load traffic of three dwords per lane, on a kernel that keeps the texture
+            // data path busier than the vector ALUs.
+            const bool left = x0 == 0 && gx == 0;   // no columns -4..-1: mirrored below
+            const uint32_t ye = (uint32_t)__mul24(reflect101(y0 - 3 + 2 * rp, L.h), pitch);
+            const uint32_t yo = (uint32_t)__mul24(reflect101(y0 - 2 + 2 * rp, L.h), pitch);
+            const uint32_t cx = (uint32_t)(x0 + 4 * gx);
+            const uint32_t e1 = load_u32_unaligned(base + ye + cx), o1 = load_u32_unaligned(base + yo + cx);
+            uint32_t he = 0, ho = 0;
+            if ((gx == 0 && !left) || gx == 15) {
+                const uint32_t hx = gx == 0 ? cx - 4 : cx + 4;
+                he = load_u32_unaligned(base + ye + hx);
+                ho = load_u32_unaligned(base + yo + hx);
+            }
+            // row_shr:1 / row_shl:1; the lane without a neighbour keeps the halo value
+            uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp((int)he, (int)e1, 0x111, 0xF, 0xF, false);
+            uint32_t e2 = (uint32_t)__builtin_amdgcn_update_dpp((int)he, (int)e1, 0x101, 0xF, 0xF, false);
+            uint32_t o0 = (uint32_t)__builtin_amdgcn_update_dpp((int)ho, (int)o1, 0x111, 0xF, 0xF, false);
+            uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ho, (int)o1, 0x101, 0xF, 0xF, false);
+            if (left) {   // columns -4..-1 are the mirror image of columns 4..1
+                e0 = __builtin_amdgcn_perm(e2, e1, 0x01020304u);
+                o0 = __builtin_amdgcn_perm(o2, o1, 0x01020304u);
             }
             uint32_t se[4], so[4];
             row4(e0, e1, e2, se);
