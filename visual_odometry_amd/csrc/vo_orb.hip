@@ -1045,7 +1045,12 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
         const float inv = 1.f / L.scale;
         const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int pitch = L.pitch;
-        const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R);
+        // The 40 bytes fetched per row start at the dword boundary at or below column cx - 18
+        // (rows of the blur block are 64-byte aligned; aligned dword loads cost the texture
+        // addresser about a quarter less than loads that straddle dwords); the 37 columns wanted
+        // begin `skew` bytes into them.
+        const int skew = (cx - DP_R) & 3;
+        const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R - skew);
         uint32_t pw[13];
 #pragma unroll
         for (int t = 0; t < 10; ++t)
@@ -1069,7 +1074,7 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
                 *reinterpret_cast<uint32_t*>(&my_patch[(16 * t + (hl >> 1)) * DP_PITCH + 32 + 4 * (hl & 1)]) = pw[10 + t];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint8_t* centre = my_patch + DP_R * DP_PITCH + DP_R;
+        const uint8_t* centre = my_patch + DP_R * DP_PITCH + DP_R + skew;
         int t0[8], t1[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
