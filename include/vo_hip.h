@@ -159,9 +159,10 @@ int vo_find_essential(vo_ctx* ctx, const float* p1, const float* p2, int n, cons
  * match_images_orb (ref:src/image_matcher.cpp:71-81) followed by estimate_motion
  * as the reference's main loop runs them (ref:src/main.cpp:162-170), with every
  * intermediate kept in HBM.  Pair p uses images 2p and 2p+1 of d_imgs.
- * d_results: n_pairs records in device memory.  The call only enqueues: the
- * RANSAC rounds run on a second stream of the context so that the next call's
- * detection overlaps them, and d_results is complete after vo_sync() (which
+ * d_results: n_pairs records in device memory.  The call only enqueues:
+ * everything behind the kNN search (ratio test, RANSAC rounds, pose recovery)
+ * runs on a second stream of the context so that the next call's detection
+ * overlaps it, and d_results is complete after vo_sync() (which
  * waits for every stream of the context; waiting on vo_ctx_stream() alone is
  * not enough). */
 int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,

@@ -65,6 +65,13 @@ int join_side(vo_ctx* c) {
     return VO_OK;
 }
 
+int join_tail(vo_ctx* c) {
+    if (!c->tail_pending) return VO_OK;
+    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+    c->tail_pending = false;
+    return VO_OK;
+}
+
 }  // namespace vo
 
 using namespace vo;
@@ -84,6 +91,7 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rdone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) {
@@ -112,6 +120,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_rdone) (void)hipEventDestroy(c->ev_rdone);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -130,6 +139,7 @@ extern "C" int vo_sync(vo_ctx* c) {
     VO_HIP(c, hipStreamSynchronize(c->side));
     VO_HIP(c, hipStreamSynchronize(c->aux));
     c->side_busy = false;
+    c->tail_pending = false;
     return VO_OK;
 }
 

@@ -60,12 +60,18 @@ struct DevBuf {
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    // The RANSAC rounds of the batched pipeline run on a second stream so that the next
-    // batch's detection (main stream) overlaps them; ev_init orders side after main, ev_rdone
-    // main after side before anything reuses the RANSAC workspace.
+    // The tail of the batched pipeline (ratio test, RANSAC rounds, pose recovery) runs on a second
+    // stream so that the next batch's detection (main stream) overlaps it; ev_init orders side
+    // after main, ev_rdone main after side before a main-stream call reuses the match buffers or
+    // the RANSAC workspace.
     hipStream_t side = nullptr;
     hipEvent_t ev_init = nullptr, ev_rdone = nullptr;
     bool side_busy = false;
+    // The pipeline's tail (ratio test, counts, RANSAC) runs on the side stream and still reads the
+    // keypoint records and the kNN table of its batch: ev_tail marks the end of those reads, and
+    // the next kernel on the main stream that overwrites them waits for it (join_tail).
+    hipEvent_t ev_tail = nullptr;
+    bool tail_pending = false;
     // FAST on level 0 needs only the input images: it runs on a third stream beside the resize
     // chain that builds the other levels (ev_fork orders it after the counter reset, ev_fast0
     // orders candidate selection after it).
@@ -102,6 +108,9 @@ void t_begin_on(vo_ctx* c, int group, hipStream_t s);
 void t_end_on(vo_ctx* c, int group, hipStream_t s);   // events on another stream of the context
 // Makes the main stream wait for work still running on the side stream.
 int join_side(vo_ctx* c);
+// Makes the main stream wait until the side stream has finished reading the previous batch's
+// keypoints and kNN table.
+int join_tail(vo_ctx* c);
 int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
 
 #define VO_HIP(c, call)                                                                   \
@@ -120,7 +129,7 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
 int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
                  int nq_max, int batch,
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
-                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch);
+                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch, hipStream_t s);
 // ransac
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
+    if (int jrc = join_tail(c)) return jrc;   // the table below may still be read by the previous batch's ratio test
     // Queries per lane.  One query per lane measures fastest on everything up to
     // 65 536 x 65 536; more queries per lane only pay once the grid is so large that the train
     // set's re-reads (one pass per workgroup) start to matter.
@@ -414,12 +415,12 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
 int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
                  int nq_max, int batch,
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
-                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch) {
+                 int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch, hipStream_t s) {
     if (batch <= 0) return VO_OK;
-    t_begin(c, VO_T_RATIO);
-    hipLaunchKernelGGL(ratio_kernel, dim3(batch), dim3(256), 0, c->stream, d_idx2, d_dist2, d_nq, cnt_stride, nq_max, ratio, d_kp1,
+    t_begin_on(c, VO_T_RATIO, s);
+    hipLaunchKernelGGL(ratio_kernel, dim3(batch), dim3(256), 0, s, d_idx2, d_dist2, d_nq, cnt_stride, nq_max, ratio, d_kp1,
                        d_kp2, kp_stride, d_qidx, d_tidx, d_dist, d_p1, d_p2, d_nmatch);
-    t_end(c, VO_T_RATIO);
+    t_end_on(c, VO_T_RATIO, s);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -479,6 +480,7 @@ extern "C" int vo_match_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t
     if ((rc = ensure(c, c->m_tidx, (size_t)nq * 4))) return rc;
     if ((rc = ensure(c, c->m_dist, (size_t)nq * 4))) return rc;
     if ((rc = ensure(c, c->m_cnt, 64))) return rc;
+    if ((rc = join_side(c))) return rc;   // a pipeline call's tail may still use the match buffers
     VO_HIP(c, hipMemcpyAsync(c->st_q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemcpyAsync(c->st_t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
     if ((rc = knn2_launch(c, (const uint8_t*)c->st_q.p, nullptr, 1, nq, 0, (const uint8_t*)c->st_t.p, nullptr, nt, 0, 1,
@@ -486,7 +488,7 @@ extern "C" int vo_match_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t
         return rc;
     if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, nullptr, 1, nq, 1, ratio, nullptr,
                            nullptr, 0, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p, (float*)c->m_dist.p, nullptr,
-                           nullptr, (int32_t*)c->m_cnt.p)))
+                           nullptr, (int32_t*)c->m_cnt.p, c->stream)))
         return rc;
     int32_t m = 0;
     VO_HIP(c, hipMemcpyAsync(&m, c->m_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));

@@ -1361,6 +1361,9 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
                            (const uint32_t*)c->tab.p, (uint8_t*)c->blur.p);
         t_end(c, VO_T_BLUR);
     }
+    // the keypoint records and counts written from here on may still be read by the previous
+    // batch's ratio test on the side stream
+    if (int jrc = join_tail(c)) return jrc;
     t_begin(c, VO_T_DESCRIBE);
     const int dbx = std::max((g.max_features + 31) / 32, 1);   // about four keypoint pairs per wavefront
     hipLaunchKernelGGL(orient_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,

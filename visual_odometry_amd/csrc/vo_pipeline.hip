@@ -48,17 +48,25 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
     if ((rc = knn2_launch(c, desc, cnt, pair_step, cap, dstride, desc + (size_t)cap * 32, cnt + 1, cap, dstride, n_pairs,
                           (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
         return rc;
+    // Everything after the kNN search - ratio test, counts, RANSAC rounds, pose recovery - is a
+    // chain of small, latency-bound kernels: it goes to the side stream, so that the main stream
+    // can start the next batch's detection right behind the matcher.  ev_tail marks the point
+    // after which the side stream no longer reads this batch's keypoints and kNN table.
+    hipStream_t side = c->side;
+    VO_HIP(c, hipEventRecord(c->ev_init, c->stream));
+    VO_HIP(c, hipStreamWaitEvent(side, c->ev_init, 0));
     if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, cnt, pair_step, cap, n_pairs,
                            ratio, kps, kps + cap, (size_t)pair_step * cap, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p,
-                           (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p)))
+                           (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p, side)))
         return rc;
+    hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, side, d_results, cnt,
+                       (const int32_t*)c->m_cnt.p, n_pairs, pair_step);
+    VO_HIP(c, hipEventRecord(c->ev_tail, side));
+    c->tail_pending = true;
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, (const int32_t*)c->m_cnt.p, cap, n_pairs,
                          K, threshold, confidence, fixed_iters, d_results, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, true)))
         return rc;
-    // (main stream, right behind the point normalisation: the counts are overwritten by the next batch)
-    hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, d_results, cnt,
-                       (const int32_t*)c->m_cnt.p, n_pairs, pair_step);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }

@@ -1620,9 +1620,13 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
                int samples_cap, bool on_side) {
     if (batch <= 0) return VO_OK;
-    // The workspace below may still be in use by the previous call's rounds on the side stream.
-    if (int jrc = join_side(c)) return jrc;
-    hipStream_t s = c->stream;
+    // on_side: the caller (the batched pipeline) has already ordered the side stream behind the
+    // matches; everything below is enqueued there, one batch after the other, so the workspace
+    // needs no further ordering.  Otherwise the work goes to the main stream, which first waits
+    // for rounds of an earlier pipeline call that may still use the workspace.
+    if (!on_side)
+        if (int jrc = join_side(c)) return jrc;
+    hipStream_t s = on_side ? c->side : c->stream;
     RParams P;
     P.ifx = 1.0 / K[0];
     P.ify = 1.0 / K[1];
@@ -1652,7 +1656,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     double* recs = (double*)c->r_best.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
 
-    t_begin(c, VO_T_RANSAC);
+    t_begin_on(c, VO_T_RANSAC, s);
     if (n_max > 0)
         hipLaunchKernelGGL(normalize_kernel, dim3((n_max + 255) / 256, batch), dim3(256), 0, s, d_p1, d_p2, d_n, n_max, P,
                            m);
@@ -1660,13 +1664,6 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int r0 = std::min(round_size(0, fixed_iters), total);
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
                        r0);
-    if (on_side) {
-        // point normalisation and the first samples stay on the main stream (they read the
-        // caller's match buffers); the rounds and the pose recovery move to the side stream
-        VO_HIP(c, hipEventRecord(c->ev_init, c->stream));
-        VO_HIP(c, hipStreamWaitEvent(c->side, c->ev_init, 0));
-        s = c->side;
-    }
     int h0 = 0;
     for (int round = 0; h0 < total; ++round) {
         int hr = std::min(round_size(round, fixed_iters), total - h0);
@@ -1716,6 +1713,9 @@ static int run_host_ransac(vo_ctx* c, const float* p1, const float* p2, int n, c
     int32_t* d_samples = samples ? (int32_t*)(base + sizeof(vo_pair_result) + 72 + 64) : nullptr;
     uint8_t* d_me = base + sizeof(vo_pair_result) + 72 + 64 + log_bytes;
     uint8_t* d_mp = d_me + nm;
+    // the staging buffers and the workspace may still be in use by a pipeline call's tail on the
+    // side stream
+    if ((rc = join_side(c))) return rc;
     if (n > 0) {
         VO_HIP(c, hipMemcpyAsync(c->m_p1.p, p1, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
         VO_HIP(c, hipMemcpyAsync(c->m_p2.p, p2, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
