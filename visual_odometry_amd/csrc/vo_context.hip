@@ -94,7 +94,8 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
@@ -123,6 +124,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
+    if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -76,7 +76,7 @@ struct vo_ctx {
     // chain that builds the other levels (ev_fork orders it after the counter reset, ev_fast0
     // orders candidate selection after it).
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_fast0 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fast0 = nullptr, ev_blur = nullptr;
     std::string err;
     unsigned timing = 0;   // bit g: kernel group g is bracketed by events
     std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)

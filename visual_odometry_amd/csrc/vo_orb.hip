@@ -1334,6 +1334,23 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         t_end(c, VO_T_FAST);
     }
     if (fast0_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_fast0, 0));
+    // The blur needs only the pyramid, candidate selection and orientation are mostly latency
+    // (LDS sorts, scattered window reads): the blur runs beside them on the auxiliary stream, which
+    // is in order behind FAST on level 0; it additionally waits for the main stream (resize chain
+    // and FAST on the upper levels) so that FAST keeps the vector ALUs to itself.  Serial, on the
+    // main stream, while one of the overlapped groups is bracketed by timing events.
+    const unsigned overlapped = (1u << VO_T_SELECT) | (1u << VO_T_BLUR) | (1u << VO_T_DESCRIBE);
+    const bool blur_aside = d_desc && fast0_aside && !(c->timing & overlapped);
+    auto launch_blur = [&](hipStream_t bs) {
+        hipLaunchKernelGGL(blur_kernel, dim3(xcd_grid((uint32_t)g.blur_tiles * N)), dim3(256), 0, bs, g, tabs, d_imgs, pyr,
+                           (const uint32_t*)c->tab.p, (uint8_t*)c->blur.p);
+    };
+    if (blur_aside) {
+        VO_HIP(c, hipEventRecord(c->ev_fork, s));
+        VO_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        launch_blur(c->aux);
+        VO_HIP(c, hipEventRecord(c->ev_blur, c->aux));
+    }
     t_begin(c, VO_T_SELECT);
     int sel_need = 0;   // upper bound of a level's list after the first cut, for the Harris grid
     for (int l = 0; l < kLevels; ++l) sel_need = std::max(sel_need, std::min(g.sel_cap, g.L[l].cand_cap));
@@ -1355,10 +1372,9 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     else VO_SELECT(8192);
 #undef VO_SELECT
     t_end(c, VO_T_SELECT);
-    if (d_desc) {
+    if (d_desc && !blur_aside) {
         t_begin(c, VO_T_BLUR);
-        hipLaunchKernelGGL(blur_kernel, dim3(xcd_grid((uint32_t)g.blur_tiles * N)), dim3(256), 0, s, g, tabs, d_imgs, pyr,
-                           (const uint32_t*)c->tab.p, (uint8_t*)c->blur.p);
+        launch_blur(s);
         t_end(c, VO_T_BLUR);
     }
     // the keypoint records and counts written from here on may still be read by the previous
@@ -1369,6 +1385,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     hipLaunchKernelGGL(orient_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
                        (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p, (const float*)c->kp_resp.p,
                        (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p);
+    if (blur_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     if (d_desc)
         hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx,
                            (const uint8_t*)c->blur.p, (const vo_keypoint*)d_kps, (const int32_t*)d_counts, d_desc, cap);
