@@ -181,17 +181,7 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
     return (a & 0xFFFFu) != 0;
 }
 
-// centre minus the 16 ring pixels (Bresenham circle of radius 3, OpenCV's order)
-__device__ __forceinline__ void ring_diffs(const uint8_t* p, int* d) {
-    constexpr int P = FP_W;
-    const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
-                         -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
-    int v = p[0];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)p[off[k]];
-}
-
-// the 16 ring pixels themselves (same order); returns the centre
+// the 16 ring pixels (Bresenham circle of radius 3, OpenCV's order); returns the centre
 __device__ __forceinline__ int ring_pixels(const uint8_t* p, int* r) {
     constexpr int P = FP_W;
     const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
@@ -202,35 +192,11 @@ __device__ __forceinline__ int ring_pixels(const uint8_t* p, int* r) {
 }
 
 // FAST-9/16 score of a pixel known to be a corner: max over 9-arcs of the arc's minimum
-// contrast (bright or dark), minus 1 - what cornerScore<16> returns.
-__device__ __forceinline__ int corner_score(const int* d) {
-    int mn[16], mx[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        mn[i] = min(d[i], d[(i + 1) & 15]);
-        mx[i] = max(d[i], d[(i + 1) & 15]);
-    }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        mn4[i] = min(mn[i], mn[(i + 2) & 15]);
-        mx4[i] = max(mx[i], mx[(i + 2) & 15]);
-    }
-    int A = -1000, B = 1000;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int a8 = min(mn4[i], mn4[(i + 4) & 15]);
-        int b8 = max(mx4[i], mx4[(i + 4) & 15]);
-        A = max(A, min(a8, d[(i + 8) & 15]));
-        B = min(B, max(b8, d[(i + 8) & 15]));
-    }
-    return max(A, -B) - 1;
-}
-
-// The same score with both polarities in one ladder of packed 16-bit operations: every ring
-// pixel r becomes the pair (d, -d) = (256 - r, r) + (centre - 256, -centre), the first pair
-// being r * 0xFFFF + 256 (no borrow: 256 - r >= 1); the low half of the result is then the
-// largest arc minimum of d and the high half that of -d.
+// contrast (bright or dark), minus 1 - what cornerScore<16> returns.  Both polarities in one
+// ladder of packed 16-bit operations: every ring pixel r becomes the pair (d, -d) =
+// (256 - r, r) + (centre - 256, -centre), the first pair being r * 0xFFFF + 256 (no borrow:
+// 256 - r >= 1); the low half of the result is then the largest arc minimum of d and the high
+// half that of -d.
 typedef short pk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int corner_score_packed(const uint8_t* p) {
     constexpr int P = FP_W;
