@@ -979,8 +979,8 @@ __global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8
 }
 
 // rBRIEF descriptors from the finished keypoint records.  Half a wavefront per keypoint: the
-// 37x37 blurred window around it goes to LDS with 13 dword loads per lane (ten sweeps of
-// 4 rows x 8 dwords, three of 16 rows x 2 dwords; all inside the level thanks to the 31-px
+// 37x37 blurred window around it goes to LDS with five 16-byte loads per lane (sweeps of
+// eight 64-byte rows; the columns wanted are inside the level thanks to the 31-px
 // keypoint margin - gathering the 512 test points from global memory instead costs one L1 tag
 // look-up per lane and test), lane t evaluates tests t, t+32, ..., t+224 on it and eight
 // ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
@@ -996,11 +996,12 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
     int pat[8];   // this lane's eight tests are the same for every keypoint
 #pragma unroll
     for (int k = 0; k < 8; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
-    const int rr = hl >> 3, dj = hl & 7;
+    const int r8 = hl >> 2, q16 = hl & 3;   // row of an eight-row sweep, 16-byte quarter of the 64-byte row
     const uint8_t* blur_img = blur + (size_t)img * g.blk_stride;
     // blurred window of +-18 px around the keypoint (the rotated test points stay inside:
-    // the pattern's largest radius is 18.4), one per half-wave, rows padded to 40 bytes
-    constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 40;
+    // the pattern's largest radius is 18.4), one per half-wave; a row holds the 64 bytes fetched
+    // for it, pitch 80
+    constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 80;
     __shared__ __attribute__((aligned(16))) uint8_t patch[8][DP_ROWS * DP_PITCH];
     uint8_t* my_patch = patch[(threadIdx.x >> 6) * 2 + half];
     for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
@@ -1011,20 +1012,20 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
         const float inv = 1.f / L.scale;
         const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int pitch = L.pitch;
-        // The 40 bytes fetched per row start at the dword boundary at or below column cx - 18
-        // (rows of the blur block are 64-byte aligned; aligned dword loads cost the texture
-        // addresser about a quarter less than loads that straddle dwords); the 37 columns wanted
-        // begin `skew` bytes into them.
-        const int skew = (cx - DP_R) & 3;
+        // A load instruction costs the texture addresser about the same for 16 bytes per lane as
+        // for 4, and what it costs grows with the number of rows it touches: a row is fetched as
+        // four aligned 16-byte quarters (64 bytes from the 16-byte boundary at or below column
+        // cx - 18; rows of the blur block are 64-byte aligned), eight rows per half-wave and
+        // instruction, five instructions instead of thirteen dword sweeps.  The 37 columns
+        // wanted begin `skew` bytes into the 64.
+        const int skew = (cx - DP_R) & 15;
         const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R - skew);
-        uint32_t pw[13];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pw[5];
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
-            pw[t] = load_u32_unaligned(blur_img + (org + (uint32_t)(__mul24(min(4 * t + rr, DP_ROWS - 1), pitch) + 4 * dj)));
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            pw[10 + t] = load_u32_unaligned(
-                blur_img + (org + (uint32_t)(__mul24(min(16 * t + (hl >> 1), DP_ROWS - 1), pitch) + 32 + 4 * (hl & 1))));
+        for (int t = 0; t < 5; ++t)
+            pw[t] = *reinterpret_cast<const u32x4*>(
+                blur_img + (org + (uint32_t)(__mul24(min(8 * t + r8, DP_ROWS - 1), pitch) + 16 * q16)));
         const float ar = kp.angle * (float)(M_PI / 180.f);
         double sd, cd;
         sincos_f64((double)ar, &sd, &cd);
@@ -1032,12 +1033,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous keypoint's reads are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int t = 0; t < 10; ++t)
-            if (4 * t + rr < DP_ROWS) *reinterpret_cast<uint32_t*>(&my_patch[(4 * t + rr) * DP_PITCH + 4 * dj]) = pw[t];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (16 * t + (hl >> 1) < DP_ROWS)
-                *reinterpret_cast<uint32_t*>(&my_patch[(16 * t + (hl >> 1)) * DP_PITCH + 32 + 4 * (hl & 1)]) = pw[10 + t];
+        for (int t = 0; t < 5; ++t)
+            if (8 * t + r8 < DP_ROWS) *reinterpret_cast<u32x4*>(&my_patch[(8 * t + r8) * DP_PITCH + 16 * q16]) = pw[t];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint8_t* centre = my_patch + DP_R * DP_PITCH + DP_R + skew;
@@ -1237,7 +1234,9 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
     size_t N = (size_t)n_images;
     int rc;
     if ((rc = ensure(c, c->pyr, N * g.blk_stride))) return rc;
-    if ((rc = ensure(c, c->blur, N * g.blk_stride))) return rc;
+    // (the descriptor kernel fetches whole 64-byte pieces of rows: up to 45 bytes past the last
+    // column it needs)
+    if ((rc = ensure(c, c->blur, N * g.blk_stride + 256))) return rc;
     if ((rc = ensure(c, c->cand, N * std::max(g.cand_stride, 1) * 4))) return rc;
     if ((rc = ensure(c, c->cand_cnt, N * kLevels * 4))) return rc;
     if ((rc = ensure(c, c->kp_x, N * g.kp_stride * 2))) return rc;
