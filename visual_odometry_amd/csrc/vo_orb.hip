@@ -896,11 +896,14 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
 }
 
 // Orientation and keypoint records.  Half a wavefront (32 lanes) per keypoint, two keypoints
-// per wave, grid-stride over an image's keypoints.  Intensity-centroid angle: the half-wave
-// sweeps the 31x31 disc in eight steps of four rows, lane = (row of the step, dword of the
-// 32-byte row window); a step is one unaligned dword load, the disc byte mask and two
-// v_dot4_u32_u8 (sum and column-weighted sum), the row weight is applied to the row sum.  The
-// first lane of the half writes the final keypoint.
+// per wave, grid-stride over an image's keypoints.  The 31 rows x 48 bytes that hold the 31x31
+// disc (from the 16-byte boundary at or below column x - 15) go to LDS with three 16-byte loads
+// per lane - a load instruction costs the texture addresser, which bounded this kernel, the
+// same for 16 bytes per lane as for 4, and less the fewer rows it touches.  Intensity-centroid
+// angle: the half-wave sweeps the disc in eight steps of four rows, lane = (row of the step,
+// dword of the 32-byte row window); a step is two aligned LDS dwords shifted into place
+// (v_alignbyte), the disc byte mask and two v_dot4_u32_u8 (sum and column-weighted sum), the row
+// weight is applied to the row sum.  The first lane of the half writes the final keypoint.
 __global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint16_t* __restrict__ kp_x,
@@ -908,6 +911,8 @@ __global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8
                                                      const float* __restrict__ kp_resp,
                                                      const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
                                                      int cap, int32_t* __restrict__ counts, uint32_t* __restrict__ flags) {
+    constexpr int OW_ROWS = 2 * kHalfPatch + 1, OW_PITCH = 48;
+    __shared__ __attribute__((aligned(16))) uint8_t win[8][OW_ROWS * OW_PITCH];
     uint32_t work;
     if (!xcd_remap((uint32_t)bx * (uint32_t)g.n_images, &work)) return;
     const int img = (int)(work / (uint32_t)bx), blk = (int)(work - (uint32_t)img * (uint32_t)bx);
@@ -928,6 +933,16 @@ __global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8
     for (int k = 0; k < 8; ++k) amask[k] = d_angle_mask[k * 32 + hl];
     const int rr = hl >> 3, dj = hl & 7;
     const uint32_t wcol = 0x03020100u + 0x04040404u * (uint32_t)dj;   // window byte index = u + 15
+    // staging: element i = 32 * t + hl of the 31 x 3 sixteen-byte pieces, row i / 3, piece i % 3
+    int srow[3], sseg[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int i = 32 * t + hl;
+        srow[t] = i / 3;
+        sseg[t] = i - 3 * srow[t];
+    }
+    uint8_t* my_win = win[(threadIdx.x >> 6) * 2 + half];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
         const bool live = o2 + half < n;          // an odd count leaves the last second half idle
         const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
@@ -942,17 +957,33 @@ __global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8
         const int x = kp_x[ib], y = kp_y[ib];
         int lpitch;
         const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
-        // every address within 16 px of a keypoint is inside the level (keypoints keep a
-        // 31-px margin): all loads are issued unconditionally and masked afterwards
-        const uint8_t* p = lbase + (size_t)(y - kHalfPatch + rr) * lpitch + (x - kHalfPatch + 4 * dj);
-        uint32_t v[8];
+        // every address within 16 px of a keypoint is inside the level (keypoints keep a 31-px
+        // margin); the 48 bytes of a row end at most one byte past column x + 16 + 15, still
+        // inside the image buffer because the rows below the window exist
+        const uint8_t* p0 = lbase + (size_t)(y - kHalfPatch) * lpitch + (x - kHalfPatch);
+        const int skew = (int)((uintptr_t)p0 & 15);   // the same for every row when the pitch is a multiple of 16
+        p0 -= skew;
+        u32x4 sv[3];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = load_u32_unaligned(p + (size_t)(4 * t) * lpitch);
+        for (int t = 0; t < 3; ++t)
+            __builtin_memcpy(&sv[t], p0 + (size_t)min(srow[t], OW_ROWS - 1) * lpitch + 16 * sseg[t], 16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous keypoint's reads are done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (srow[t] < OW_ROWS) *reinterpret_cast<u32x4*>(&my_win[srow[t] * OW_PITCH + 16 * sseg[t]]) = sv[t];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // this lane's dword of step t starts skew + 4 * dj bytes into row 4 * t + rr
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(my_win) + rr * (OW_PITCH / 4) + ((skew >> 2) + dj);
+        const uint32_t sh = (uint32_t)skew & 3u;
         uint32_t S = 0, X = 0;
         int m01 = 0;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            uint32_t val = v[t] & amask[t];
+            // (rows 31 of the last step do not exist: their mask is empty, the address is clamped)
+            const uint32_t* q = wp + min(4 * t, OW_ROWS - 1 - rr) * (OW_PITCH / 4);
+            uint32_t val = __builtin_amdgcn_alignbyte(q[1], q[0], sh) & amask[t];
             uint32_t rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
             X = __builtin_amdgcn_udot4(val, wcol, X, false);
             S += rs;
