@@ -589,22 +589,35 @@ __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* _
     if (tid == 0) sel_cnt[img * kLevels + l] = M;
 }
 
-__global__ __launch_bounds__(256) void harris_kernel(Geom g, int cap, int bx, const uint8_t* __restrict__ in,
+// One lane per surviving candidate.  A level gets as many 256-lane blocks as its list after the
+// first cut normally needs (2 * quota plus a margin; hb.first[l] .. hb.first[l + 1]) and the
+// blocks stride over the list, so ties at the cut that make it longer are still covered; sizing
+// every level for the longest possible list launched four times as many workgroups as had work,
+// and the kernel ran at the rate workgroups can be dispatched.
+struct HarrisBlocks {
+    int first[kLevels + 1];
+};
+__global__ __launch_bounds__(256) void harris_kernel(Geom g, int cap, HarrisBlocks hb, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint32_t* __restrict__ sel_keys,
                                                      const uint32_t* __restrict__ sel_cnt, float* __restrict__ sel_resp) {
+    const int per_img = hb.first[kLevels];
     uint32_t work;
-    if (!xcd_remap((uint32_t)bx * kLevels * (uint32_t)g.n_images, &work)) return;
-    const int img = (int)(work / (uint32_t)(bx * kLevels));
-    const int rem = (int)(work - (uint32_t)img * (uint32_t)(bx * kLevels));
-    const int l = rem / bx;
-    const int i = (rem - l * bx) * 256 + threadIdx.x;
-    if (i >= (int)sel_cnt[img * kLevels + l]) return;
-    size_t o = ((size_t)img * kLevels + l) * cap + i;
-    uint32_t k = sel_keys[o];
+    if (!xcd_remap((uint32_t)per_img * (uint32_t)g.n_images, &work)) return;
+    const int img = (int)(work / (uint32_t)per_img);
+    const int rem = (int)(work - (uint32_t)img * (uint32_t)per_img);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kLevels; ++k) l += (rem >= hb.first[k]);
+    const int nblk = hb.first[l + 1] - hb.first[l];
+    const int count = (int)sel_cnt[img * kLevels + l];
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
-    sel_resp[o] = harris_at(base, pitch, k & 0xFFF, k >> 12);
+    for (int i = (rem - hb.first[l]) * 256 + (int)threadIdx.x; i < count; i += nblk * 256) {
+        size_t o = ((size_t)img * kLevels + l) * cap + i;
+        uint32_t k = sel_keys[o];
+        sel_resp[o] = harris_at(base, pitch, k & 0xFFF, k >> 12);
+    }
 }
 
 template <int CAP>
@@ -1348,15 +1361,18 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         VO_HIP(c, hipEventRecord(c->ev_blur, c->aux));
     }
     t_begin(c, VO_T_SELECT);
-    int sel_need = 0;   // upper bound of a level's list after the first cut, for the Harris grid
-    for (int l = 0; l < kLevels; ++l) sel_need = std::max(sel_need, std::min(g.sel_cap, g.L[l].cand_cap));
-    const int hbx = std::max((sel_need + 255) / 256, 1);
+    HarrisBlocks hb;
+    hb.first[0] = 0;
+    for (int l = 0; l < kLevels; ++l) {
+        const int expect = std::min(2 * g.L[l].quota + 64, std::min(g.sel_cap, g.L[l].cand_cap));
+        hb.first[l + 1] = hb.first[l] + std::max((expect + 255) / 256, 1);
+    }
 #define VO_SELECT(CAPV)                                                                                              \
     do {                                                                                                             \
         hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
                            (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
                            (uint32_t*)c->flags.p);                                                                   \
-        hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hbx * kLevels * N)), dim3(256), 0, s, g, CAPV, hbx, d_imgs, \
+        hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hb.first[kLevels] * N)), dim3(256), 0, s, g, CAPV, hb, d_imgs, \
                            pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
         hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g,                              \
                            (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
