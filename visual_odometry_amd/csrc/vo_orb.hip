@@ -487,23 +487,82 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-template <typename T>
-__device__ void bitonic_sort_asc(T* s, int P, int tid, int nt) {
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += nt) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    T a = s[i], b = s[ixj];
-                    bool asc = (i & k) == 0;
-                    if ((a > b) == asc) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
-                }
+// Bitonic sorting network for the 512-thread selection kernels with the elements in registers:
+// thread t holds elements E*t .. E*t + E - 1.  Compare-exchange distances below E stay inside a thread,
+// distances below 64*E are lane shuffles inside a wavefront, and only the larger ones go through
+// LDS with a workgroup barrier each - 9 barriers instead of 55 for 1024 elements.
+template <int E>
+__device__ void bitonic_sort_regs(uint32_t* s, int P, int tid) {
+    constexpr int NT = 512;
+    const bool act = E * tid < P;
+    uint32_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = act ? s[E * tid + e] : 0xFFFFFFFFu;
+    for (int k = 2; k <= P; k <<= 1) {
+        int j = k >> 1;
+        if (j >= 64 * E) {
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[E * tid + e] = v[e];
             }
             __syncthreads();
+            for (; j >= 64 * E; j >>= 1) {
+                for (int i = tid; i < P; i += NT) {
+                    int ixj = i ^ j;
+                    if (ixj > i) {
+                        uint32_t a = s[i], b = s[ixj];
+                        bool asc = (i & k) == 0;
+                        if ((a > b) == asc) {
+                            s[i] = b;
+                            s[ixj] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = s[E * tid + e];
+            }
         }
+        for (; j >= E; j >>= 1) {   // partner in another lane of the wavefront
+            const int lx = j / E;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = E * tid + e;
+                const uint32_t w = (uint32_t)__shfl_xor((int)v[e], lx);
+                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                v[e] = keep_min ? min(v[e], w) : max(v[e], w);
+            }
+        }
+#pragma unroll
+        for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // partner in the same thread
+            if (jj > j) continue;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (e & jj) continue;
+                const bool asc = ((E * tid + e) & k) == 0;
+                const uint32_t lo = min(v[e], v[e | jj]), hi = max(v[e], v[e | jj]);
+                v[e] = asc ? lo : hi;
+                v[e | jj] = asc ? hi : lo;
+            }
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[E * tid + e] = v[e];
+    }
+    __syncthreads();
+}
+
+// P (a power of two, at most CAP) elements of s ascending, 512 threads.
+template <int CAP>
+__device__ void sort_asc_512(uint32_t* s, int P, int tid) {
+    if (P <= 512) bitonic_sort_regs<1>(s, P, tid);
+    else if (P == 1024) bitonic_sort_regs<2>(s, P, tid);
+    else if (P == 2048) bitonic_sort_regs<4>(s, P, tid);
+    else if (CAP >= 4096 && P == 4096) bitonic_sort_regs<8>(s, P, tid);
+    else if (CAP >= 8192) bitonic_sort_regs<16>(s, P, tid);
 }
 
 // Selection runs as three kernels so that the per-candidate image reads (Harris) are
@@ -583,7 +642,7 @@ __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* _
     while (P < (int)M) P <<= 1;
     for (int i = M + tid; i < P; i += NT) keys[i] = 0xFFFFFFFFu;
     __syncthreads();
-    bitonic_sort_asc(keys, P, tid, NT);   // raster order: key = y << 12 | x
+    sort_asc_512<CAP>(keys, P, tid);   // raster order: key = y << 12 | x
     uint32_t* out = sel_keys + ((size_t)img * kLevels + l) * CAP;
     for (int i = tid; i < (int)M; i += NT) out[i] = keys[i];
     if (tid == 0) sel_cnt[img * kLevels + l] = M;
@@ -650,7 +709,7 @@ __global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* _
     __syncthreads();
     uint32_t inv_thr = 0xFFFFFFFFu;   // keep iff inv <= inv_thr
     if (M > quota) {
-        bitonic_sort_asc(srt, P, tid, NT);
+        sort_asc_512<CAP>(srt, P, tid);
         inv_thr = srt[quota - 1];
         __syncthreads();
     }
