@@ -976,7 +976,7 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
 // dword of the 32-byte row window); a step is two aligned LDS dwords shifted into place
 // (v_alignbyte), the disc byte mask and two v_dot4_u32_u8 (sum and column-weighted sum), the row
 // weight is applied to the row sum.  The first lane of the half writes the final keypoint.
-__global__ __launch_bounds__(256) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint16_t* __restrict__ kp_x,
                                                      const uint16_t* __restrict__ kp_y,
