@@ -425,3 +425,42 @@ def test_pipeline_sequence_equals_pairwise(ctx):
     b = np.frombuffer(r_pair.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
     assert (a["n_kp1"] > 500).all() and (a["n_matches"] >= 0).all()
     assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
+def test_host_calls_between_async_pipeline_calls(ctx, oracle):
+    """The pipeline's tail (ratio test, RANSAC) runs on a side stream and still reads the kNN table
+    and the keypoint records of its batch; host-buffer calls that reuse those buffers on the
+    main stream (matcher, detector) must wait for it, and must not disturb the batches in flight."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for p in range(3):
+        frames += list(synth.frame_pair(520 + p))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+
+    def run(res):
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 3, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res.data_ptr())
+
+    ref = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    run(ref)
+    ctx.sync()
+    ref = ref.cpu().numpy().tobytes()
+    q, t = synth.descriptors(31, 700), synth.descriptors(32, 900)
+    oi, od = oracle.knn2(q, t)
+    img = synth.frame_pair(77)[0]
+    ok, odesc = oracle.orb_detect(img, 800)
+    for rep in range(3):
+        r1 = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        r2 = torch.zeros_like(r1)
+        torch.cuda.synchronize()
+        run(r1)
+        gi, gd = ctx.hamming_knn2(q, t)          # shares the kNN table with the batch in flight
+        run(r2)
+        gk, gdesc = ctx.orb_detect(img, 800)     # re-plans the detector for another batch shape
+        ctx.sync()
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+        assert gk.tobytes() == ok.tobytes() and np.array_equal(gdesc, odesc)
+        assert r1.cpu().numpy().tobytes() == ref
+        assert r2.cpu().numpy().tobytes() == ref
