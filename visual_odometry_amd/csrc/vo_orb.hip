@@ -371,7 +371,10 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             // ring masks through the sign bit: mask = (mask << 1) | sign(thr -+ (centre - ring))
             // is one add and one v_alignbit per ring pixel and polarity (the reversed bit order
             // keeps arcs contiguous)
-            const int kb = kFastThr - v, kd = kFastThr + v;
+            int kb = kFastThr - v, kd = kFastThr + v;
+            // (opaque to the optimiser, which otherwise re-associates kb + r into (r - v) + thr:
+            // one instruction more per ring pixel)
+            asm volatile("" : "+v"(kb), "+v"(kd));
             unsigned bright = 0, dark = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
