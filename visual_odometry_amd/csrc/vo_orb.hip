@@ -834,6 +834,7 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     };
 
     if (direct) {
+        const bool inner_rows = y0 >= 3 && y0 + BT_H + 3 <= L.h;   // source rows y0 - 3 .. y0 + 60 exist
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
@@ -843,8 +844,12 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
             // of the load traffic of three dwords per lane, on a kernel that keeps the texture
             // data path busier than the vector ALUs.
             const bool left = x0 == 0 && gx == 0;   // no columns -4..-1: mirrored below
-            const uint32_t ye = (uint32_t)__mul24(reflect101(y0 - 3 + 2 * rp, L.h), pitch);
-            const uint32_t yo = (uint32_t)__mul24(reflect101(y0 - 2 + 2 * rp, L.h), pitch);
+            int re = y0 - 3 + 2 * rp, ro = re + 1;
+            if (!inner_rows) {   // workgroup-uniform: only tiles at the top or bottom border reflect
+                re = reflect101(re, L.h);
+                ro = reflect101(ro, L.h);
+            }
+            const uint32_t ye = (uint32_t)__mul24(re, pitch), yo = (uint32_t)__mul24(ro, pitch);
             const uint32_t cx = (uint32_t)(x0 + 4 * gx);
             const uint32_t e1 = load_u32_unaligned(base + ye + cx), o1 = load_u32_unaligned(base + yo + cx);
             uint32_t he = 0, ho = 0;
