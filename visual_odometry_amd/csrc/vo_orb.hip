@@ -1153,7 +1153,16 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             if (8 * t + r8 < DP_ROWS) *reinterpret_cast<u32x4*>(&my_patch[(8 * t + r8) * DP_PITCH + 16 * q16]) = pw[t];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint8_t* centre = my_patch + DP_R * DP_PITCH + DP_R + skew;
+        // cvRound of a rotated coordinate v, |v| < 2^22: the float sum v + 1.5 * 2^23 is rounded to
+        // an integer half-to-even like rint, and its bit pattern is 0x4B400000 + rint(v) - one
+        // fast-class add instead of v_rndne + v_cvt; the bias is folded into the window offset
+        // (the 24-bit multiply sees 0x400000 + row).
+        constexpr float kRound = 12582912.f;
+        const uint32_t cbase = (uint32_t)(DP_R * DP_PITCH + DP_R + skew) - 0x400000u * (uint32_t)DP_PITCH - 0x4B400000u;
+        auto tap = [&](float rx, float ry) -> int {
+            const uint32_t bx = __float_as_uint(rx + kRound), by = __float_as_uint(ry + kRound);
+            return my_patch[__umul24(by, (uint32_t)DP_PITCH) + bx + cbase];
+        };
         int t0[8], t1[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -1161,8 +1170,8 @@ __global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uin
             float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
             float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
             float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-            t0[k] = centre[__mul24(__float2int_rn(ry0), DP_PITCH) + __float2int_rn(rx0)];
-            t1[k] = centre[__mul24(__float2int_rn(ry1), DP_PITCH) + __float2int_rn(rx1)];
+            t0[k] = tap(rx0, ry0);
+            t1[k] = tap(rx1, ry1);
         }
         uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
 #pragma unroll
