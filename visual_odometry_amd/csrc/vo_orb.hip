@@ -408,9 +408,10 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         int X = x0 + ix, Y = y0 + iy;
         if (ix < 0 || iy < 0 || ix >= FT_W || iy >= FT_H || X >= L.w - kEdge || Y >= L.h - kEdge) continue;
         const uint8_t* s = &sc[sy * FS_W + sx];
-        int v = s[0];
-        bool keep = v > s[-1] && v > s[1] && v > s[-FS_W - 1] && v > s[-FS_W] && v > s[-FS_W + 1] && v > s[FS_W - 1] &&
-                    v > s[FS_W] && v > s[FS_W + 1];
+        // all nine reads issued together (a short-circuit chain is nine LDS round trips in a row)
+        const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-FS_W - 1], n3 = s[-FS_W], n4 = s[-FS_W + 1], n5 = s[FS_W - 1],
+                  n6 = s[FS_W], n7 = s[FS_W + 1];
+        const bool keep = v > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
         if (keep) {
             uint32_t slot = atomicAdd(&nlist, 1u);
             list[slot] = ((uint32_t)v << 24) | ((uint32_t)Y << 12) | (uint32_t)X;
