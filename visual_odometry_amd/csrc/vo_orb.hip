@@ -1076,11 +1076,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             m01 += (4 * t - kHalfPatch + rr) * (int)rs;
         }
         int m10 = (int)X - kHalfPatch * (int)S;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
+        // sum over the 32 lanes of the half: four DPP steps inside a row of 16 lanes (pairs, quads,
+        // half-row mirror, row mirror - no LDS round trip), one shuffle across the two rows
+        auto row_sum = [](int x) -> int {
+            x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+            x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+            x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+            x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);   // row_mirror
+            return x;
+        };
+        m10 = row_sum(m10);
+        m01 = row_sum(m01);
+        m10 += __shfl_xor(m10, 16);
+        m01 += __shfl_xor(m01, 16);
         if (hl == 0 && live) {
             vo_keypoint k;
             k.x = (float)x * L.scale;
