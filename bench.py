@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (height, width, max_features, fixed_iters, default pairs per step)
-    "c2_640x480_2000kp": (480, 640, 2000, 0, 256),
-    "c3_kitti_1241x376_4000kp": (376, 1241, 4000, 0, 128),
+    "c2_640x480_2000kp": (480, 640, 2000, 0, 512),
+    "c3_kitti_1241x376_4000kp": (376, 1241, 4000, 0, 256),
     "c5_1080p_10000kp_4096hyp": (1080, 1920, 10000, 4096, 32),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak

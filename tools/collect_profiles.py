@@ -43,7 +43,7 @@ cw = per_kernel(latest("gpurun_out/pmc_traffic/calib_WRITE_SIZE/**/*counter_coll
 groups = {"fast": ("fast_kernel", 1), "blur": ("blur_kernel", 1), "describe": ("describe_kernel", 1),
           "resize": ("resize_kernel", 7)}   # seven resize launches per step
 out = {
-    "workload": "c2_640x480_2000kp", "pairs_per_step": 256,
+    "workload": d["config"]["workload"], "pairs_per_step": d["config"]["pairs_per_step_per_gpu"],
     "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "bench.py --steps 3 --warmup 1 --streams 1 --no-sequence; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.  Calibration "
               f"(tools/calib_fetch, same passes): a 1 GiB read reports FETCH_SIZE {cf['read_dword']:.0f} KiB with dword "
@@ -59,7 +59,7 @@ print(out["bytes_per_launch"])
 if glob.glob(os.path.join(R, "gpurun_out/pmc_sq/a/**/*counter_collection.csv"), recursive=True):
     import subprocess
     js = subprocess.run([sys.executable, os.path.join(R, "tools/pmc_sq_json.py"), os.path.join(R, "gpurun_out/pmc_sq/a"),
-                         os.path.join(R, "gpurun_out/pmc_sq/b")], check=True, capture_output=True, text=True).stdout
+                         os.path.join(R, "gpurun_out/pmc_sq/b"), str(d["config"]["pairs_per_step_per_gpu"])], check=True, capture_output=True, text=True).stdout
     open(os.path.join(R, "profiles/pmc_sq.json"), "w").write(js)
     k = json.loads(js)["kernels"]
     for name in ("fast_kernel", "blur_kernel", "describe_kernel", "orient_kernel", "knn2_kernel", "resize_kernel"):

@@ -22,7 +22,7 @@ SIMDS = 256 * 4
 
 per = collections.defaultdict(lambda: collections.defaultdict(dict))   # kernel -> dispatch -> counter -> value
 meta = {}
-for d in sys.argv[1:]:
+for d in sys.argv[1:3]:
     files = sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     if not files:
         continue
@@ -48,7 +48,7 @@ for name, disp in per.items():
     if "SQ_INSTS_VALU" in row:
         row["valu_issue_frac"] = row["SQ_INSTS_VALU"] * 4.0 / (SIMDS * row["duration_ns"] * CLOCK_GHZ)
     out[name] = row
-print(json.dumps({"workload": "c2_640x480_2000kp", "pairs_per_step": 256, "source": "tools/pmc_sq.sh (two rocprofv3 --pmc passes over bench.py --steps 3 --warmup 1 "
+print(json.dumps({"workload": "c2_640x480_2000kp", "pairs_per_step": int(sys.argv[3]) if len(sys.argv) > 3 else 512, "source": "tools/pmc_sq.sh (two rocprofv3 --pmc passes over bench.py --steps 3 --warmup 1 "
                             "--no-hamming --no-cpu-baseline --no-sequence), averaged by tools/pmc_sq_json.py over all "
                             "dispatches of a kernel; durations are those under counter collection",
                   "clock_ghz": CLOCK_GHZ, "simds": SIMDS, "kernels": out}, indent=1))

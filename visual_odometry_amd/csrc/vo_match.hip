@@ -368,10 +368,14 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     if (nq_max <= 0 || batch <= 0) return VO_OK;
     if (int jrc = join_tail(c)) return jrc;   // the table below may still be read by the previous batch's ratio test
     // Queries per lane.  One query per lane measures fastest on everything up to
-    // 65 536 x 65 536; more queries per lane only pay once the grid is so large that the train
-    // set's re-reads (one pass per workgroup) start to matter.
-    int qpl = 4;
-    while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
+    // 65 536 x 65 536 (a train set of 2 MB stays in the L2 caches, whatever the batch); more
+    // queries per lane only pay once the train set is larger and the grid so large that its
+    // re-reads (one pass per workgroup) start to matter.
+    int qpl = 1;
+    if (nt_max > 65536) {
+        qpl = 4;
+        while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
+    }
     if (const char* e = getenv("VO_KNN_QPL")) {   // tuning aid
         int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) qpl = v;
