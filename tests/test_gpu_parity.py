@@ -350,6 +350,36 @@ def test_pipeline_pairs_matches_oracle(ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfeat", [64, 128, 190])
+def test_pipeline_tied_responses_return_more_than_max_features(ctx, oracle, nfeat):
+    """A tiled texture repeats every corner, the detector keeps all ties of the last retained
+    response (as the library's retainBest does), and an image ends up with more keypoints than
+    max_features: every stage after the detector must carry the surplus (the capacity of the
+    per-image tables is max_features plus slack, not max_features)."""
+    import torch
+    from visual_odometry_amd import capi
+    rng = np.random.default_rng(8)
+    blk = np.kron(rng.integers(0, 256, (24, 24), dtype=np.uint8), np.ones((5, 5), np.uint8))
+    a = np.tile(blk, (5, 6))[:480, :640].copy()
+    b = np.roll(a, (2, 3), (0, 1)).copy()
+    ka, da = oracle.orb_detect(a, nfeat)
+    kb, db = oracle.orb_detect(b, nfeat)
+    assert len(ka) > nfeat, "the scene no longer produces a surplus: pick another texture"
+    qi, ti, _ = oracle.match(da, db)
+    imgs = torch.from_numpy(np.stack([a, b, b, a])).cuda()
+    res = torch.zeros(2 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_pairs_dev(imgs.data_ptr(), 2, 480, 640, 640, 480 * 640, nfeat, 0.75, TUM_K, 1.0, 0.999, 0,
+                           res.data_ptr())
+    ctx.sync()
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    assert (out[0]["n_kp1"], out[0]["n_kp2"], out[0]["n_matches"]) == (len(ka), len(kb), len(qi))
+    qi2, _, _ = oracle.match(db, da)
+    assert (out[1]["n_kp1"], out[1]["n_kp2"], out[1]["n_matches"]) == (len(kb), len(ka), len(qi2))
+    o = oracle.estimate_motion(np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1), TUM_K)
+    assert bool(out[0]["valid"]) == o["valid"] and out[0]["inliers"] == o["inliers"]
+
+
+@pytest.mark.gpu
 def test_pipeline_back_to_back_calls_are_independent(ctx):
     """Calls only enqueue (the RANSAC rounds of one call overlap the detection of the next on a
     second stream): a burst of calls with different batches, one sync at the end, must give each
