@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int
 
 static int round_size(int round, int fixed) {
     if (fixed > 0) return 512;
-    static const int sz[] = {64, 64, 128, 256, 488};
+    static const int sz[] = {32, 96, 128, 256, 488};
     return round < 5 ? sz[round] : 0;
 }
 
