@@ -125,7 +125,8 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
 int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
 // match
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
-                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2);
+                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2,
+                int nq_typical = 0);   // expected query count when nq_max is only a capacity (picks the workgroup size)
 int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
                  int nq_max, int batch,
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,

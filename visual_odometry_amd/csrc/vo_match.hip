@@ -14,6 +14,7 @@
 // knn2_kernel<QPL> (several queries per lane, very large batches) fetches it
 // through the scalar cache and uses it as the scalar operand.
 #include <cstdlib>
+#include <algorithm>
 
 #include "vo_internal.h"
 
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 }
 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
-                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2) {
+                const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2,
+                int nq_typical) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
     if (int jrc = join_tail(c)) return jrc;   // the table below may still be read by the previous batch's ratio test
     // Queries per lane.  One query per lane measures fastest on everything up to
@@ -389,19 +391,30 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     const int mode = mode_env ? atoi(mode_env) : 1;
     if (qpl == 1 && mode >= 1) {
         // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
-        // still has several to switch between
+        // still has several to switch between.  Many (a batch of some hundred pairs): one
+        // wavefront per workgroup - it then sees every train row of its queries, improves on its
+        // two best about a third as often as four wavefronts with a quarter of the rows each
+        // (2 ln n events per query against 4 x 2 ln(n/4)), and nothing is left to merge; 7 % less
+        // kernel time at 512 pairs, but only with 12 or more wavefronts per SIMD to draw from.
         const long long wgs = (long long)grid.x * grid.y;
-        int nw = wgs * 4 >= 8 * 1024 ? 4 : wgs * 8 >= 8 * 1024 ? 8 : 16;
+        const int nq_live = nq_typical > 0 ? std::min(nq_typical, nq_max) : nq_max;
+        const long long live = (long long)((nq_live + 63) / 64) * batch;
+        int nw = live >= 12 * 1024 ? 1 : wgs * 4 >= 8 * 1024 ? 4 : wgs * 8 >= 8 * 1024 ? 8 : 16;
         if (mode == 4 || mode == 8 || mode == 16) nw = mode;
-        if (nw == 4)
-            hipLaunchKernelGGL(knn2_bcast_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
-                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
-        else if (nw == 8)
-            hipLaunchKernelGGL(knn2_bcast_kernel<8>, grid, dim3(512), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
-                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
-        else
-            hipLaunchKernelGGL(knn2_bcast_kernel<16>, grid, dim3(1024), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t,
-                               d_nt, nt_max, t_stride, d_idx2, d_dist2);
+        if (const char* e = getenv("VO_KNN_NW")) {   // tuning aid
+            const int v = atoi(e);
+            if (v == 1 || v == 4 || v == 8 || v == 16) nw = v;
+        }
+#define VO_KNN_LAUNCH(NW)                                                                                              \
+    hipLaunchKernelGGL(knn2_bcast_kernel<NW>, grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, \
+                       d_nt, nt_max, t_stride, d_idx2, d_dist2)
+        switch (nw) {
+            case 1: VO_KNN_LAUNCH(1); break;
+            case 4: VO_KNN_LAUNCH(4); break;
+            case 8: VO_KNN_LAUNCH(8); break;
+            default: VO_KNN_LAUNCH(16); break;
+        }
+#undef VO_KNN_LAUNCH
     } else if (qpl == 4)
         hipLaunchKernelGGL(knn2_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);

@@ -46,7 +46,7 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
     if ((rc = orb_run(c, d_imgs, kps, desc, cap, cnt))) return rc;
     const size_t dstride = (size_t)pair_step * cap * 32;
     if ((rc = knn2_launch(c, desc, cnt, pair_step, cap, dstride, desc + (size_t)cap * 32, cnt + 1, cap, dstride, n_pairs,
-                          (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p)))
+                          (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p, max_features)))
         return rc;
     // Everything after the kNN search - ratio test, counts, RANSAC rounds, pose recovery - is a
     // chain of small, latency-bound kernels: it goes to the side stream, so that the main stream
