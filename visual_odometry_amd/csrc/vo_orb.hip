@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     __shared__ uint16_t q1[FQ_N], q2[FQ_N];
     __shared__ uint32_t list[FT_W * FT_H / 4];
     __shared__ uint32_t n1, n2, nlist, gbase;
+    __shared__ uint32_t colmask[32];
 
     uint32_t work;
     if (!xcd_remap(ntiles * (uint32_t)g.n_images, &work)) return;
@@ -270,6 +271,20 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         nlist = 0;
     }
     for (int i = tid; i < FS_H * FS_W / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    // LDS column of score column 0: x0 = kEdge + 64k, so (x0 - 4) & ~3 = x0 - 7 and x0 - 1 - ax0 = 6
+    static_assert(kEdge % 4 == 3 && FT_W % 4 == 0, "the score region starts at LDS column 6");
+    constexpr int cx0 = 6;
+    constexpr int g0 = cx0 >> 2, ng = ((cx0 + FT_W + 1) >> 2) - g0 + 1;   // dword groups that hold score columns
+    const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
+    if (tid < ng) {
+        // pre-test result bits (9, 10, 25, 26: pixels 0..3) of the group's columns that are score
+        // columns 0 .. lim_x: the same for every row, so looked up instead of recomputed per group
+        const int lim_x = min(FT_W + 1, max_sx);
+        const int sx0 = 4 * (g0 + tid) - cx0;
+        const int lo = max(-sx0, 0), hi = min(lim_x - sx0 + 1, 4);
+        const uint32_t nib = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        colmask[tid] = ((nib & 3u) << 9) | ((nib & 12u) << 23);
+    }
 
     bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
     if (aligned) {
@@ -302,19 +317,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     // field set iff centre - ring > thr and ring + (K - centre) iff ring - centre > thr (no
     // carry crosses a field: all values stay in [236, 746]).  A 9-arc contains two adjacent
     // cardinals, i.e. (S | N) & (E | W) for one polarity.
-    // LDS column of score column 0: x0 = kEdge + 64k, so (x0 - 4) & ~3 = x0 - 7 and x0 - 1 - ax0 = 6
-    static_assert(kEdge % 4 == 3 && FT_W % 4 == 0, "the score region starts at LDS column 6");
-    constexpr int cx0 = 6;
-    const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
     {
         constexpr int PD = FP_W / 4;   // dwords per LDS row
         const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
-        constexpr int g0 = cx0 >> 2, ng = ((cx0 + FT_W + 1) >> 2) - g0 + 1;
-        const int lim_x = min(FT_W + 1, max_sx), lim_y = min(FS_H - 1, max_sy);
+        const int lim_y = min(FS_H - 1, max_sy);
         constexpr uint32_t KK = (uint32_t)(511 - kFastThr) * 0x00010001u, EV = 0x00FF00FFu, FL = 0x02000200u;
         for (int i0 = 0; i0 < ng * FS_H; i0 += 256) {
             const int i = i0 + tid;
-            const int sy = i / ng, gi = g0 + (i - sy * ng);
+            const int sy = i / ng, gk = i - sy * ng, gi = g0 + gk;
             uint32_t T = 0;   // bits 9, 10, 25, 26: pixels 0..3 of the group pass
             if (sy <= lim_y) {
                 const int idx = (sy + 3) * PD + gi;
@@ -329,12 +339,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                                     (((Se + de) | (Ne + de)) & ((Ee + de) | (We + de)));
                 const uint32_t po = (((bo - So) | (bo - No)) & ((bo - Eo) | (bo - Wo))) |
                                     (((So + dn) | (No + dn)) & ((Eo + dn) | (Wo + dn)));
-                T = (pe & FL) | ((po & FL) << 1);
-                // columns of the group that are score columns 0 .. lim_x
-                const int sx0 = 4 * gi - cx0;
-                const int lo = max(-sx0, 0), hi = min(lim_x - sx0 + 1, 4);
-                const uint32_t nib = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-                T &= ((nib & 3u) << 9) | ((nib & 12u) << 23);
+                T = ((pe & FL) | ((po & FL) << 1)) & colmask[gk];
             }
             const unsigned long long m0 = __ballot(T & (1u << 9)), m1 = __ballot(T & (1u << 10));
             const unsigned long long m2 = __ballot(T & (1u << 25)), m3 = __ballot(T & (1u << 26));
@@ -376,10 +381,18 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             // one instruction more per ring pixel)
             asm volatile("" : "+v"(kb), "+v"(kd));
             unsigned bright = 0, dark = 0;
+            // the 32 plain adds as one run (they issue faster in runs), then the 32 v_alignbit
+            unsigned sb[16], sd[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                bright = __builtin_amdgcn_alignbit(bright, (unsigned)(kb + r[k]), 31);
-                dark = __builtin_amdgcn_alignbit(dark, (unsigned)(kd - r[k]), 31);
+                sb[k] = (unsigned)(kb + r[k]);
+                sd[k] = (unsigned)(kd - r[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bright = __builtin_amdgcn_alignbit(bright, sb[k], 31);
+                dark = __builtin_amdgcn_alignbit(dark, sd[k], 31);
             }
             // a ring pixel is in at most one of the masks, so only the one with nine or more
             // bits can hold an arc: one arc test instead of two
