@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
 // ------------------------------------------------------------------ FAST
 constexpr int FT_W = 64, FT_H = 32;
 constexpr int FP_W = 80, FP_H = FT_H + 8;   // pixel tile (dword-aligned origin, 4-px halo)
-constexpr int FS_W = 68, FS_H = FT_H + 2;   // score tile (1-px halo), logical width FT_W + 2
+constexpr int FS_W = FP_W, FS_H = FT_H + 2;   // score tile (1-px halo), logical width FT_W + 2; the pixel tile's pitch,
+                                              // so that a queue entry (byte offset into the pixel tile) also addresses the score
 constexpr int FQ_N = FS_H * (FT_W + 2);     // positions whose score is needed
 
 __device__ __forceinline__ bool has_arc9(unsigned m) {
@@ -353,7 +354,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
                 return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
             };
-            const uint16_t pos = (uint16_t)(sy * (FT_W + 2) + 4 * gi - cx0);
+            // queue entry: byte offset of the pixel in the LDS pixel tile
+            const uint16_t pos = (uint16_t)((sy + 3) * FP_W + 4 * gi);
             if (T & (1u << 9)) q1[slot(m0, qb)] = pos;
             if (T & (1u << 10)) q1[slot(m1, qb + c0)] = (uint16_t)(pos + 1);
             if (T & (1u << 25)) q1[slot(m2, qb + c0 + c1)] = (uint16_t)(pos + 2);
@@ -370,9 +372,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         uint16_t pos = 0;
         if (i < c1) {
             pos = q1[i];
-            int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
             int r[16];
-            const int v = ring_pixels(&px[(sy + 3) * FP_W + cx0 + sx], r);
+            const int v = ring_pixels(&px[pos], r);
             // ring masks through the sign bit: mask = (mask << 1) | sign(thr -+ (centre - ring))
             // is one add and one v_alignbit per ring pixel and polarity (the reversed bit order
             // keeps arcs contiguous)
@@ -404,23 +405,24 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
 
-    // stage 3: corner scores
+    // stage 3: corner scores (score (sy, sx) lives at the pixel's tile offset minus sc_shift)
+    constexpr int sc_shift = 3 * FP_W + cx0;
+    static_assert(FS_W == FP_W, "one offset addresses both tiles");
     const uint32_t c2 = n2;
     for (uint32_t i = tid; i < c2; i += 256) {
-        uint16_t pos = q2[i];
-        int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
-        sc[sy * FS_W + sx] = (uint8_t)corner_score_packed(&px[(sy + 3) * FP_W + cx0 + sx]);
+        const uint16_t pos = q2[i];
+        sc[pos - sc_shift] = (uint8_t)corner_score_packed(&px[pos]);
     }
     __syncthreads();
 
     // 3x3 non-max suppression + border filter on the interior (only corners need the look-up)
     for (uint32_t i = tid; i < c2; i += 256) {
-        uint16_t pos = q2[i];
-        int sy = pos / (FT_W + 2), sx = pos - sy * (FT_W + 2);
+        const uint16_t pos = q2[i];
+        const int sy = pos / FP_W - 3, sx = pos - (sy + 3) * FP_W - cx0;
         int ix = sx - 1, iy = sy - 1;
         int X = x0 + ix, Y = y0 + iy;
         if (ix < 0 || iy < 0 || ix >= FT_W || iy >= FT_H || X >= L.w - kEdge || Y >= L.h - kEdge) continue;
-        const uint8_t* s = &sc[sy * FS_W + sx];
+        const uint8_t* s = &sc[pos - sc_shift];
         // all nine reads issued together (a short-circuit chain is nine LDS round trips in a row)
         const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-FS_W - 1], n3 = s[-FS_W], n4 = s[-FS_W + 1], n5 = s[FS_W - 1],
                   n6 = s[FS_W], n7 = s[FS_W + 1];
