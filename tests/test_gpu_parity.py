@@ -34,6 +34,27 @@ def test_knn2_matches_oracle(ctx, oracle, nq, nt):
     assert np.array_equal(gd, od)
 
 
+@pytest.mark.parametrize("knob", ["VO_KNN_NW=1", "VO_KNN_NW=4", "VO_KNN_NW=8", "VO_KNN_NW=16", "VO_KNN_MODE=0",
+                                  "VO_KNN_QPL=2", "VO_KNN_QPL=4"])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (70, 3), (300, 257), (2000, 2000), (1500, 70000)])
+def test_knn2_every_launch_variant(ctx, oracle, monkeypatch, knob, nq, nt):
+    """The matcher picks its kernel and workgroup size from the problem size (one wavefront per
+    workgroup only for batches of several hundred pairs, the scalar-operand kernels only beyond
+    65 536 train rows): every variant is forced here, on shapes with ragged last blocks, ties at
+    distance 0 and a train set longer than one 65 536-row chunk."""
+    name, value = knob.split("=")
+    monkeypatch.setenv(name, value)   # read by the library at every launch
+    q = synth.descriptors(300 + nq, nq, dup_fraction=0.2)
+    t = synth.descriptors(400 + nt, nt, dup_fraction=0.3)
+    if nt > 100 and nq > 50:
+        t[-50:] = q[:50]
+        t[7:57] = q[:50]
+    gi, gd = ctx.hamming_knn2(q, t)
+    oi, od = oracle.knn2(q, t)
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(gd, od)
+
+
 def test_knn2_empty_train(ctx):
     q = synth.descriptors(1, 10)
     gi, gd = ctx.hamming_knn2(q, np.zeros((0, 32), np.uint8))
