@@ -401,6 +401,34 @@ def test_pipeline_tied_responses_return_more_than_max_features(ctx, oracle, nfea
 
 
 @pytest.mark.gpu
+def test_pipeline_results_do_not_depend_on_matcher_variant(ctx, monkeypatch):
+    """The batched matcher launch (per-pair counts, strided descriptor tables) with every kernel
+    variant forced: the pair records must be byte-identical to the default launch's, which the
+    tests above check against the oracle."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for p in range(3):
+        frames += list(synth.frame_pair(70 + p))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+
+    def run():
+        res = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 3, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res.data_ptr())
+        ctx.sync()
+        return res.cpu().numpy().tobytes()
+
+    want = run()
+    assert np.frombuffer(want, capi.PAIR_DTYPE)["n_matches"].min() > 50
+    for knob in ["VO_KNN_NW=1", "VO_KNN_NW=4", "VO_KNN_NW=8", "VO_KNN_MODE=0", "VO_KNN_QPL=2", "VO_KNN_QPL=4"]:
+        name, value = knob.split("=")
+        monkeypatch.setenv(name, value)
+        assert run() == want, knob
+        monkeypatch.delenv(name)
+
+
+@pytest.mark.gpu
 def test_pipeline_back_to_back_calls_are_independent(ctx):
     """Calls only enqueue (the RANSAC rounds of one call overlap the detection of the next on a
     second stream): a burst of calls with different batches, one sync at the end, must give each
