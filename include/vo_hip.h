@@ -133,6 +133,22 @@ int vo_hamming_knn2_dev(vo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* 
 int vo_match_ratio(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio,
                    int32_t* query_idx, int32_t* train_idx, float* distance, int* n_out);
 
+/* The device-resident form of vo_match_ratio for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  The kNN(2)
+ * table between the search and the ratio test lives in a workspace that is part
+ * of the library's code object (16 bytes per query row, VO_STATIC_MAX_QUERIES
+ * rows = 512 KiB on every GPU the library runs on, held until the process ends),
+ * so the call performs no hipMalloc / hipFree and only enqueues two kernels on
+ * the context's stream.  d_q: nq x 32, d_t: nt x 32 (16-byte aligned); outputs
+ * hold up to nq entries, *d_n_out the number written; all in device memory and
+ * valid once the stream has run.  nq > VO_STATIC_MAX_QUERIES -> VO_ERR_CAPACITY.
+ * All contexts of one GPU share that GPU's workspace: calls that overlap on one
+ * GPU (two contexts, two host threads) race and must be serialised by the caller. */
+#define VO_STATIC_MAX_QUERIES 32768
+int vo_match_ratio_static(vo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, float ratio,
+                          int32_t* d_query_idx, int32_t* d_train_idx, float* d_distance, int32_t* d_n_out);
+
 /* --- estimate_motion -----------------------------------------------------------
  * Replaces visual_odometry::estimate_motion (ref:src/motion_estimator.cpp:44-95):
  * cv::findEssentialMat(RANSAC, confidence, threshold, 1000 iterations, 5-point

@@ -23,7 +23,7 @@ PAIR_DTYPE = np.dtype(
 EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
-    "vo_hamming_knn2_dev", "vo_match_ratio", "vo_estimate_motion", "vo_find_essential",
+    "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
     "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
 
@@ -68,6 +68,7 @@ def load():
     lib.vo_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp, vp]
     lib.vo_hamming_knn2_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
     lib.vo_match_ratio.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, C.POINTER(i)]
+    lib.vo_match_ratio_static.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, vp]
     lib.vo_estimate_motion.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_find_essential.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
@@ -227,6 +228,11 @@ class Context:
 
     def hamming_knn2_dev(self, d_q, nq, d_t, nt, d_idx2, d_dist2):
         self._check(self.lib.vo_hamming_knn2_dev(self.h, d_q, nq, d_t, nt, d_idx2, d_dist2), "vo_hamming_knn2_dev")
+
+    def match_ratio_static(self, d_q, nq, d_t, nt, ratio, d_query_idx, d_train_idx, d_distance, d_n_out):
+        """vo_match_ratio on device buffers with the library's static workspace (allocates nothing)."""
+        self._check(self.lib.vo_match_ratio_static(self.h, d_q, nq, d_t, nt, ratio, d_query_idx, d_train_idx,
+                                                   d_distance, d_n_out), "vo_match_ratio_static")
 
     def pipeline_pairs_dev(self, d_imgs, n_pairs, rows, cols, step, image_stride, max_features, ratio, K, threshold,
                            confidence, fixed_iters, d_results):

@@ -99,6 +99,10 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
+    if (static_scratch_init(c) != VO_OK) {
+        vo_ctx_destroy(c);
+        return VO_ERR_HIP;
+    }
     *out = c;
     return VO_OK;
 }

@@ -131,6 +131,9 @@ int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const
                  int nq_max, int batch,
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,
                  int32_t* d_tidx, float* d_dist, float* d_p1, float* d_p2, int32_t* d_nmatch, hipStream_t s);
+// Resolves, once per GPU, the device address of the static workspace of vo_match_ratio_static
+// (called by vo_ctx_create with the context's device current).
+int static_scratch_init(vo_ctx* c);
 // ransac
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,

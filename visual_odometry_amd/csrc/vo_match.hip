@@ -15,6 +15,7 @@
 // through the scalar cache and uses it as the scalar operand.
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 
 #include "vo_internal.h"
 
@@ -442,9 +443,72 @@ int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const
     return VO_OK;
 }
 
+// ------------------------------------------------------------------ static workspace
+// Workspace of vo_match_ratio_static: the kNN(2) table (nearest two train rows and their
+// distances per query) that the search kernel writes and the ratio kernel reads.  It lives in
+// the code object instead of in hipMalloc memory, so that the entry point allocates nothing.
+// Every GPU the library runs on holds its own copy (512 KiB) until the process ends.
+constexpr int kStaticMaxQueries = VO_STATIC_MAX_QUERIES;
+static __device__ __align__(256) int32_t scratch[kStaticMaxQueries * 4];   // idx2 [n][2], then dist2 [n][2]
+
+// Device address of `scratch` on each GPU.  In host code the array's name is only a handle for
+// the runtime, not an address a kernel can use: the address is asked for once per device
+// (vo_ctx_create, with that device current) and kernels receive the pointer kept here.
+constexpr int kMaxDevices = 64;
+static int32_t* g_scratch_ptr[kMaxDevices] = {nullptr};
+static std::mutex g_scratch_mutex;
+
+int static_scratch_init(vo_ctx* c) {
+    if (c->device < 0 || c->device >= kMaxDevices)
+        return fail(c, VO_ERR_INVALID, "static workspace: device index beyond " + std::to_string(kMaxDevices - 1));
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[c->device]) return VO_OK;
+    void* p = nullptr;
+    VO_HIP(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(c, VO_ERR_HIP, "static workspace: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[c->device] = (int32_t*)p;
+    return VO_OK;
+}
+
 }  // namespace vo
 
 using namespace vo;
+
+extern "C" int vo_match_ratio_static(vo_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, float ratio,
+                                     int32_t* d_query_idx, int32_t* d_train_idx, float* d_distance,
+                                     int32_t* d_n_out) {
+    if (!c) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || !d_n_out || (nq > 0 && (!d_q || !d_query_idx || !d_train_idx || !d_distance)) ||
+        (nt > 0 && !d_t))
+        return fail(c, VO_ERR_INVALID, "vo_match_ratio_static: bad argument");
+    if (((uintptr_t)d_q | (uintptr_t)d_t) & 15)
+        return fail(c, VO_ERR_INVALID, "vo_match_ratio_static: descriptor arrays must be 16-byte aligned");
+    if (nq > kStaticMaxQueries)
+        return fail(c, VO_ERR_CAPACITY, "vo_match_ratio_static: " + std::to_string(nq) + " query rows exceed the static workspace of " +
+                                            std::to_string(kStaticMaxQueries) + " (VO_STATIC_MAX_QUERIES)");
+    int32_t* ws = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;
+    if (!ws) return fail(c, VO_ERR_HIP, "vo_match_ratio_static: the static workspace of this device was not set up");
+    VO_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // The table needs no clearing: the search writes both entries of every query row below nq
+    // (-1 where a neighbour is missing) and the ratio kernel reads only those rows; rows left
+    // from a larger earlier call are never looked at.  Empty inputs give a count of 0, written by
+    // the ratio kernel itself (nq = 0: no row passes; nt = 0: every neighbour is -1).
+    int32_t* idx2 = ws;
+    int32_t* dist2 = ws + (size_t)kStaticMaxQueries * 2;
+    if (nq > 0) {
+        // one query per lane, train rows broadcast from LDS; four wavefronts per workgroup suit
+        // every size this entry point admits
+        dim3 grid((nq + 63) / 64, 1);
+        hipLaunchKernelGGL(knn2_bcast_kernel<4>, grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
+                           (const int32_t*)nullptr, nt, (size_t)0, idx2, dist2);
+    }
+    hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)idx2, (const int32_t*)dist2,
+                       (const int32_t*)nullptr, 1, nq, ratio, (const vo_keypoint*)nullptr, (const vo_keypoint*)nullptr,
+                       (size_t)0, d_query_idx, d_train_idx, d_distance, (float*)nullptr, (float*)nullptr, d_n_out);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
 
 extern "C" int vo_hamming_knn2_dev(vo_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2,
                                    int32_t* d_dist2) {
