@@ -45,7 +45,21 @@ typedef struct vo_pair_result {
     int32_t n_kp1, n_kp2;
     int32_t n_matches;
     int32_t ransac_iters;
+    int32_t status;   /* VO_TRUNC_* bits of the pair's two images; 0 = complete */
+    int32_t reserved;
 } vo_pair_result;
+
+/* A keypoint list of an image did not fit an internal table or the caller's
+ * capacity and was cut (deterministically: the entries first in raster order
+ * are kept).  OpenCV's retainBest keeps every candidate tied with the last one
+ * retained, so on images with thousands of equal scores the lists are
+ * unbounded; the tables hold 2 x quota + 512 (at least 2048) candidates per
+ * level after the FAST-score cut and quota + 256 keypoints per level. */
+enum {
+    VO_TRUNC_SCORE_LIST = 1,    /* ties at the FAST-score cut (2 x level quota) */
+    VO_TRUNC_KEYPOINT_LIST = 2, /* ties at the Harris-response cut (level quota) */
+    VO_TRUNC_OUTPUT = 4         /* more keypoints than the output capacity `cap` */
+};
 
 enum {
     VO_OK = 0,
@@ -66,6 +80,10 @@ const char* vo_last_error(const vo_ctx* ctx);
  * detection call is ordered after all of it.  vo_pipeline_*_dev also use a
  * second internal stream that is NOT joined - see there. */
 void* vo_ctx_stream(vo_ctx* ctx);
+/* Waits for every stream of the context.  Returns VO_ERR_CAPACITY (message:
+ * which stage) if any detection enqueued since the last report truncated a
+ * keypoint list - device-resident calls cannot report that themselves, they
+ * only enqueue.  The condition is reported once and then cleared. */
 int vo_sync(vo_ctx* ctx);
 /* Kernel timing with HIP events recorded on the stream a kernel group runs on.
  * vo_set_timing(ctx, groups) takes a bit mask (1 << VO_T_*, VO_T_ALL for every

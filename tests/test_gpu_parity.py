@@ -179,6 +179,62 @@ def test_capacity_overflow_is_loud(ctx):
         ctx.orb_detect(img, 2000, cap=100)
 
 
+def _dot_grid(spacing):
+    """Isolated bright pixels on black: each is a FAST corner of score 254 with the same Harris
+    response, so both retainBest cuts land inside one huge group of ties."""
+    img = np.zeros((480, 640), np.uint8)
+    img[4::spacing, 4::spacing] = 255
+    return img
+
+
+@pytest.mark.parametrize("spacing,bit,stage", [(8, 1, "FAST-score selection"), (12, 2, "Harris selection")])
+def test_truncated_keypoint_lists_are_reported_on_the_device_resident_path(ctx, oracle, spacing, bit, stage):
+    """OpenCV's retainBest keeps every tie of the last retained score, the GPU tables are finite:
+    when a level's list does not fit, the call must not pass silently.  Device-resident calls only
+    enqueue, so the report comes from vo_sync (once), the pair records carry the bit, and the cut
+    list is the same on every run (first in raster order), not whichever lanes won a slot."""
+    import torch
+    from visual_odometry_amd import capi
+    a = _dot_grid(spacing)
+    ok, _ = oracle.orb_detect(a, 2000)
+    per_level = np.bincount(ok["octave"], minlength=8)
+    assert per_level[0] > (2048 if bit == 1 else 434 + 256), "the scene no longer overflows: pick another spacing"
+    b = synth.frame_pair(7)[0]                                  # an ordinary image: its pairs stay clean
+    imgs = torch.from_numpy(np.stack([a, b, b, b, b, a])).cuda()
+    runs = []
+    for rep in range(2):
+        res = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 3, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res.data_ptr())
+        with pytest.raises(capi.VoError, match=stage):
+            ctx.sync()
+        ctx.sync()                                              # reported once, then cleared
+        out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+        # (a list cut at the score stage is still longer than a level's keypoint table: both bits)
+        status = capi.TRUNC_SCORE_LIST | capi.TRUNC_KEYPOINT_LIST if bit == 1 else capi.TRUNC_KEYPOINT_LIST
+        assert list(out["status"]) == [status, 0, status]
+        runs.append(out.tobytes())
+    assert runs[0] == runs[1]
+    # the detector alone: same report, and a deterministic (raster-first) cut of the level-0 list
+    kps = [torch.zeros(4096 * capi.KP_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k in kps:
+        ctx.orb_detect_batch_dev(imgs.data_ptr(), 1, 480, 640, 640, 480 * 640, 2000, k.data_ptr(), None, 4096,
+                                 cnt.data_ptr())
+        with pytest.raises(capi.VoError, match=stage):
+            ctx.sync()
+    n = int(cnt.item())
+    g = [np.frombuffer(k.cpu().numpy().tobytes(), capi.KP_DTYPE)[:n] for k in kps]
+    assert g[0].tobytes() == g[1].tobytes()
+    lvl0 = g[0][g[0]["octave"] == 0]
+    want0 = ok[ok["octave"] == 0][: len(lvl0)]                  # the oracle's list is in raster order
+    assert len(lvl0) == 434 + 256                               # level quota + slack
+    assert lvl0.tobytes() == want0.tobytes()
+    with pytest.raises(capi.VoError, match=stage):              # host-buffer entry point: error code
+        ctx.orb_detect(a, 2000)
+    ctx.sync()
+
+
 # ------------------------------------------------------------------ RANSAC / pose
 def _matched_points(oracle, seed, nfeat=2000):
     a, b = synth.frame_pair(seed)

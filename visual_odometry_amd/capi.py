@@ -17,7 +17,8 @@ KP_DTYPE = np.dtype(
 )
 PAIR_DTYPE = np.dtype(
     [("R", "<f8", (9,)), ("t", "<f8", (3,)), ("inliers", "<i4"), ("valid", "<i4"),
-     ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"), ("ransac_iters", "<i4")]
+     ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"), ("ransac_iters", "<i4"),
+     ("status", "<i4"), ("reserved", "<i4")]
 )
 
 EXPORTS = [
@@ -27,6 +28,7 @@ EXPORTS = [
     "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
 ]
 
+TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac"]
 
 _lib = None

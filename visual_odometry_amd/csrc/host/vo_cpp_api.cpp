@@ -224,9 +224,11 @@ auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& 
         for (int r = 0; r < rows; ++r) std::memcpy(&packed[i * image_bytes + (size_t)r * cols], frames[i].ptr<uint8_t>(r), cols);
     std::vector<vo_pair_result> rec(frames.size() - 1);
     double const K[4] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy};
-    if (!ok(vo_pipeline_sequence(c, packed.data(), (int)frames.size(), rows, cols, cols, image_bytes, max_features,
-                                 ratio_threshold, K, config.ransac_threshold, config.ransac_confidence, 0, rec.data())))
-        return steps;
+    int const rc = vo_pipeline_sequence(c, packed.data(), (int)frames.size(), rows, cols, cols, image_bytes, max_features,
+                                        ratio_threshold, K, config.ransac_threshold, config.ransac_confidence, 0, rec.data());
+    // a truncated keypoint list (VO_ERR_CAPACITY) still yields every record: keep them, leave the
+    // message in last_error()
+    if (!ok(rc) && rc != VO_ERR_CAPACITY) return steps;
     steps.resize(rec.size());
     for (size_t i = 0; i < rec.size(); ++i) {
         sequence_step& s = steps[i];

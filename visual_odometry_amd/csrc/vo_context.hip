@@ -72,6 +72,21 @@ int join_tail(vo_ctx* c) {
     return VO_OK;
 }
 
+int take_truncation(vo_ctx* c, const char* who) {
+    if (!c->flags.p) return VO_OK;
+    uint32_t bits = 0;
+    VO_HIP(c, hipMemcpy(&bits, c->flags.p, 4, hipMemcpyDeviceToHost));
+    if (!bits) return VO_OK;
+    VO_HIP(c, hipMemset(c->flags.p, 0, 4));
+    std::string what;
+    if (bits & VO_TRUNC_SCORE_LIST) what += " [FAST-score selection: ties at the 2 x quota cut exceed the selection table]";
+    if (bits & VO_TRUNC_KEYPOINT_LIST) what += " [Harris selection: ties at the quota cut exceed a level's keypoint table]";
+    if (bits & VO_TRUNC_OUTPUT) what += " [output: more keypoints than the caller's capacity]";
+    return fail(c, VO_ERR_CAPACITY,
+                std::string(who) + ": a keypoint list was truncated since the last report (results of the images "
+                                   "concerned are incomplete; vo_pair_result.status names the pairs):" + what);
+}
+
 }  // namespace vo
 
 using namespace vo;
@@ -114,7 +129,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
-                      &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->st_img,   &c->st_kps,   &c->st_desc,
+                      &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->img_status, &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->m_top2,   &c->m_qidx,
                       &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
                       &c->r_models, &c->r_nmodels, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_res,
@@ -146,7 +161,7 @@ extern "C" int vo_sync(vo_ctx* c) {
     VO_HIP(c, hipStreamSynchronize(c->aux));
     c->side_busy = false;
     c->tail_pending = false;
-    return VO_OK;
+    return take_truncation(c, "vo_sync");
 }
 
 extern "C" int vo_set_timing(vo_ctx* c, int groups) {

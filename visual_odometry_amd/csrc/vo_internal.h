@@ -87,7 +87,13 @@ struct vo_ctx {
     vo::Geom g{};
     bool geom_valid = false;
     std::vector<uint32_t> h_tab;   // resize tables (host copy)
-    vo::DevBuf tab, pyr, blur, cand, cand_cnt, kp_x, kp_y, kp_resp, kp_cnt, flags, sel_keys, sel_resp, sel_cnt;
+    vo::DevBuf tab, pyr, blur, cand, cand_cnt, kp_x, kp_y, kp_resp, kp_cnt, sel_keys, sel_resp, sel_cnt;
+    // Truncation bits (VO_TRUNC_*): `flags` is one sticky word per context that every kernel able
+    // to truncate a list ORs into and that only take_truncation() clears; `img_status` holds one
+    // word per image of the most recent detection call.
+    vo::DevBuf flags, img_status;
+    uint32_t* img_status_cur = nullptr;   // the half of img_status the most recent detection call uses
+    int status_phase = 0;
     const uint8_t* last_imgs = nullptr;
     // staging for the host-buffer entry points
     vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist;
@@ -112,6 +118,9 @@ int join_side(vo_ctx* c);
 // keypoints and kNN table.
 int join_tail(vo_ctx* c);
 int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
+// Reads and clears the context's sticky truncation word (the streams must have been waited for):
+// VO_OK if it was zero, else VO_ERR_CAPACITY with the stages named in the error message.
+int take_truncation(vo_ctx* c, const char* who);
 
 #define VO_HIP(c, call)                                                                   \
     do {                                                                                  \

@@ -601,10 +601,10 @@ template <int CAP>
 __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* __restrict__ cand,
                                                        const uint32_t* __restrict__ cand_cnt,
                                                        uint32_t* __restrict__ sel_keys, uint32_t* __restrict__ sel_cnt,
-                                                       uint32_t* __restrict__ flags) {
+                                                       uint32_t* __restrict__ flags, uint32_t* __restrict__ img_status) {
     __shared__ uint32_t keys[CAP];
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_n, s_thr;
+    __shared__ uint32_t s_n, s_thr, s_ge, s_cnt;
 
     // image index fastest: consecutive workgroups go to different XCDs, and with the level
     // fastest one XCD would get every image's (largest) level-0 list
@@ -644,24 +644,56 @@ __global__ __launch_bounds__(512) void select_a_kernel(Geom g, const uint32_t* _
             else if (suf >= need) s = tid * 4;
             unsigned long long m = __ballot(s >= 0);
             int top = 63 - __builtin_clzll(m);   // total > 2*quota guarantees m != 0
-            if (tid == top) s_thr = (uint32_t)s;
+            if (tid == top) {
+                s_thr = (uint32_t)s;
+                // number of candidates with a score >= s
+                const int k = s - tid * 4;
+                s_ge = above + (k <= 3 ? h3 : 0u) + (k <= 2 ? h2 : 0u) + (k <= 1 ? h1 : 0u) + (k <= 0 ? h0 : 0u);
+            }
         }
         __syncthreads();
         thr_score = s_thr;
     }
+    // Scores are 8-bit, so the cut can land in a large group of equal scores; all of them stay
+    // (retainBest keeps ties).  When that makes the list longer than the LDS table, the call is
+    // flagged as truncated and the table is filled with everything above the cut score plus the
+    // first cut-score candidates in raster order - the same set on every run, not whichever
+    // lanes won a slot: key_cut = the largest K with |{score == cut, key < K}| <= room, found
+    // bit by bit (keys are unique inside a level).
+    uint32_t key_cut = 0x01000000u;
+    if (thr_score > 0 && s_ge > (uint32_t)CAP) {
+        const uint32_t room = (uint32_t)CAP - (s_ge - hist[thr_score]);   // fewer than 2 * quota lie above the cut
+        uint32_t K = 0;
+        for (int bit = 23; bit >= 0; --bit) {
+            const uint32_t trial = K | (1u << bit);
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            uint32_t mine = 0;
+            for (uint32_t i = tid; i < total; i += NT) {
+                const uint32_t c = cl[i];
+                mine += ((c >> 24) == thr_score && (c & 0x00FFFFFFu) < trial) ? 1u : 0u;
+            }
+            if (mine) atomicAdd(&s_cnt, mine);
+            __syncthreads();
+            if (s_cnt <= room) K = trial;
+            __syncthreads();
+        }
+        key_cut = K;
+        if (tid == 0) {
+            atomicOr(flags, (uint32_t)VO_TRUNC_SCORE_LIST);
+            atomicOr(&img_status[img], (uint32_t)VO_TRUNC_SCORE_LIST);
+        }
+    }
     for (uint32_t i = tid; i < total; i += NT) {
         uint32_t c = cl[i];
-        if ((c >> 24) >= thr_score) {
+        const uint32_t sc = c >> 24, key = c & 0x00FFFFFFu;
+        if (sc > thr_score || (sc == thr_score && key < key_cut)) {
             uint32_t slot = atomicAdd(&s_n, 1u);
-            if (slot < (uint32_t)CAP) keys[slot] = c & 0x00FFFFFFu;
+            if (slot < (uint32_t)CAP) keys[slot] = key;
         }
     }
     __syncthreads();
-    uint32_t M = s_n;
-    if (M > (uint32_t)CAP) {
-        if (tid == 0) atomicOr(flags, 1u);
-        M = CAP;
-    }
+    const uint32_t M = min(s_n, (uint32_t)CAP);   // (s_n <= CAP by construction)
     int P = 1;
     while (P < (int)M) P <<= 1;
     for (int i = M + tid; i < P; i += NT) keys[i] = 0xFFFFFFFFu;
@@ -708,7 +740,8 @@ __global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* _
                                                        const uint32_t* __restrict__ sel_cnt,
                                                        const float* __restrict__ sel_resp, uint16_t* __restrict__ kp_x,
                                                        uint16_t* __restrict__ kp_y, float* __restrict__ kp_resp,
-                                                       uint32_t* __restrict__ kp_cnt, uint32_t* __restrict__ flags) {
+                                                       uint32_t* __restrict__ kp_cnt, uint32_t* __restrict__ flags,
+                                                       uint32_t* __restrict__ img_status) {
     __shared__ uint32_t inv[CAP];    // ~sortable(response): ascending == best first
     __shared__ uint32_t srt[CAP];
     __shared__ uint32_t wsum[8];
@@ -768,8 +801,9 @@ __global__ __launch_bounds__(512) void select_b_kernel(Geom g, const uint32_t* _
         __syncthreads();
     }
     if (tid == 0) {
-        if (base_out > F_cap) {
-            atomicOr(flags, 2u);
+        if (base_out > F_cap) {   // the first F_cap in raster order were kept
+            atomicOr(flags, (uint32_t)VO_TRUNC_KEYPOINT_LIST);
+            atomicOr(&img_status[img], (uint32_t)VO_TRUNC_KEYPOINT_LIST);
             base_out = F_cap;
         }
         kp_cnt[img * kLevels + l] = base_out;
@@ -1011,7 +1045,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                      const uint16_t* __restrict__ kp_y,
                                                      const float* __restrict__ kp_resp,
                                                      const uint32_t* __restrict__ kp_cnt, vo_keypoint* __restrict__ kps,
-                                                     int cap, int32_t* __restrict__ counts, uint32_t* __restrict__ flags) {
+                                                     int cap, int32_t* __restrict__ counts, uint32_t* __restrict__ flags,
+                                                     uint32_t* __restrict__ img_status) {
     constexpr int OW_ROWS = 2 * kHalfPatch + 1, OW_PITCH = 48;
     __shared__ __attribute__((aligned(16))) uint8_t win[8][OW_ROWS * OW_PITCH];
     uint32_t work;
@@ -1026,7 +1061,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int total = start[kLevels];
     if (blk == 0 && threadIdx.x == 0) {
         counts[img] = min(total, cap);
-        if (total > cap) atomicOr(flags, 4u);
+        if (total > cap) {   // the first `cap` in level-major raster order are returned
+            atomicOr(flags, (uint32_t)VO_TRUNC_OUTPUT);
+            atomicOr(&img_status[img], (uint32_t)VO_TRUNC_OUTPUT);
+        }
     }
     const int n = min(total, cap);
     uint32_t amask[8];   // this lane's disc masks are the same for every keypoint
@@ -1395,7 +1433,11 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
     if ((rc = ensure(c, c->sel_resp, N * kLevels * (size_t)g.sel_cap * 4))) return rc;
     if ((rc = ensure(c, c->sel_cnt, N * kLevels * 4))) return rc;
     if ((rc = ensure(c, c->kp_cnt, N * kLevels * 4))) return rc;
-    if ((rc = ensure(c, c->flags, 256))) return rc;
+    if ((rc = ensure(c, c->img_status, 2 * N * 4))) return rc;
+    if (!c->flags.p) {
+        if ((rc = ensure(c, c->flags, 256))) return rc;
+        VO_HIP(c, hipMemsetAsync(c->flags.p, 0, 256, c->stream));
+    }
     return VO_OK;
 }
 
@@ -1407,7 +1449,14 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     c->last_imgs = d_imgs;
     const uint8_t* pyr = (const uint8_t*)c->pyr.p;
     VO_HIP(c, hipMemsetAsync(c->cand_cnt.p, 0, (size_t)N * kLevels * 4, s));
-    VO_HIP(c, hipMemsetAsync(c->flags.p, 0, 256, s));
+    // per-image truncation bits of this call; c->flags is the context's sticky word and is only
+    // cleared by whoever reports it (take_truncation)
+    // (two halves used alternately: the previous call's words may still be read by its tail on the
+    // side stream; the call before that is done with them, because the previous call's orientation
+    // kernel was ordered behind that tail)
+    c->status_phase ^= 1;
+    c->img_status_cur = (uint32_t*)c->img_status.p + (size_t)c->status_phase * (c->img_status.bytes / 8);
+    VO_HIP(c, hipMemsetAsync(c->img_status_cur, 0, (size_t)N * 4, s));
     // level 0 (needs only the input) and the other levels are separate FAST launches
     const uint32_t tiles0 = (uint32_t)(kLevels > 1 ? g.L[1].fast_tile0 : g.fast_tiles);
     const uint32_t tiles_up = (uint32_t)g.fast_tiles - tiles0;
@@ -1476,13 +1525,14 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     do {                                                                                                             \
         hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
                            (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
-                           (uint32_t*)c->flags.p);                                                                   \
+                           (uint32_t*)c->flags.p, c->img_status_cur);                                       \
         hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hb.first[kLevels] * N)), dim3(256), 0, s, g, CAPV, hb, d_imgs, \
                            pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
         hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g,                              \
                            (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
                            (const float*)c->sel_resp.p, (uint16_t*)c->kp_x.p, (uint16_t*)c->kp_y.p,                  \
-                           (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p);                     \
+                           (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p,                      \
+                           c->img_status_cur);                                                              \
     } while (0)
     if (g.sel_cap == 2048) VO_SELECT(2048);
     else if (g.sel_cap == 4096) VO_SELECT(4096);
@@ -1501,7 +1551,8 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     const int dbx = std::max((g.max_features + 31) / 32, 1);   // about four keypoint pairs per wavefront
     hipLaunchKernelGGL(orient_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
                        (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p, (const float*)c->kp_resp.p,
-                       (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p);
+                       (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p,
+                       c->img_status_cur);
     if (blur_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     if (d_desc)
         hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx,
@@ -1548,11 +1599,9 @@ extern "C" int vo_orb_detect(vo_ctx* c, const uint8_t* img, int rows, int cols, 
                       desc_out ? (uint8_t*)c->st_desc.p : nullptr, cap, (int32_t*)c->st_cnt.p)))
         return rc;
     int32_t n = 0;
-    uint32_t flags = 0;
     VO_HIP(c, hipMemcpyAsync(&n, c->st_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipMemcpyAsync(&flags, c->flags.p, 4, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    if (flags) return fail(c, VO_ERR_CAPACITY, "vo_orb_detect: list overflow (flags " + std::to_string(flags) + ")");
+    if ((rc = take_truncation(c, "vo_orb_detect"))) return rc;
     if (n > 0) {
         VO_HIP(c, hipMemcpyAsync(kps_out, c->st_kps.p, (size_t)n * sizeof(vo_keypoint), hipMemcpyDeviceToHost,
                                  c->stream));

@@ -9,12 +9,15 @@ namespace vo {
 // image of pair p: first = p * pair_step, second = first + 1 (pair_step 2: independent
 // pairs, 1: consecutive frames of a sequence)
 __global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32_t* __restrict__ kp_cnt,
-                                   const int32_t* __restrict__ nmatch, int n_pairs, int pair_step) {
+                                   const int32_t* __restrict__ nmatch, const uint32_t* __restrict__ img_status,
+                                   int n_pairs, int pair_step) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     res[p].n_kp1 = kp_cnt[pair_step * p];
     res[p].n_kp2 = kp_cnt[pair_step * p + 1];
     res[p].n_matches = nmatch[p];
+    res[p].status = (int32_t)(img_status[pair_step * p] | img_status[pair_step * p + 1]);
+    res[p].reserved = 0;
 }
 
 }  // namespace vo
@@ -60,7 +63,7 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
                            (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p, side)))
         return rc;
     hipLaunchKernelGGL(fill_counts_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, side, d_results, cnt,
-                       (const int32_t*)c->m_cnt.p, n_pairs, pair_step);
+                       (const int32_t*)c->m_cnt.p, (const uint32_t*)c->img_status_cur, n_pairs, pair_step);
     VO_HIP(c, hipEventRecord(c->ev_tail, side));
     c->tail_pending = true;
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, (const int32_t*)c->m_cnt.p, cap, n_pairs,
@@ -110,7 +113,9 @@ extern "C" int vo_pipeline_sequence(vo_ctx* c, const uint8_t* imgs, int n_frames
     if ((rc = pipeline_run(c, (const uint8_t*)c->st_img.p, n_frames, n_frames - 1, 1, rows, cols, step, image_stride,
                            max_features, ratio, K, threshold, confidence, fixed_iters, (vo_pair_result*)c->r_res.p)))
         return rc;
-    if ((rc = vo_sync(c))) return rc;   // both streams: the records are complete
+    rc = vo_sync(c);   // every stream: the records are complete
+    if (rc != VO_OK && rc != VO_ERR_CAPACITY) return rc;
+    // on a truncated keypoint list the records still go out (status names the pairs concerned)
     VO_HIP(c, hipMemcpy(results, c->r_res.p, res_bytes, hipMemcpyDeviceToHost));
-    return VO_OK;
+    return rc;
 }
