@@ -27,9 +27,25 @@ def test_header_symbols_are_exported():
     assert sorted(capi.EXPORTS) == names
 
 
-def test_struct_layouts_match_the_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """Sizes and field offsets of the two records, as a C compiler lays out include/vo_hip.h."""
     assert capi.KP_DTYPE.itemsize == 28          # cv::KeyPoint layout
-    assert capi.PAIR_DTYPE.itemsize == 9 * 8 + 3 * 8 + 6 * 4
+    fields = {"vo_keypoint": list(capi.KP_DTYPE.names), "vo_pair_result": list(capi.PAIR_DTYPE.names)}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "vo_hip.h"', "int main(void) {"]
+    for st, names in fields.items():
+        lines.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for n in names:
+            lines.append(f'printf("{st}.{n} %zu\\n", offsetof({st}, {n}));')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, dt in (("vo_keypoint", capi.KP_DTYPE), ("vo_pair_result", capi.PAIR_DTYPE)):
+        assert int(got[st]) == dt.itemsize
+        for n in dt.names:
+            assert int(got[f"{st}.{n}"]) == dt.fields[n][1], f"{st}.{n}"
 
 
 def test_pattern_tables_agree():
