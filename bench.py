@@ -12,7 +12,7 @@ Frame pairs are independent, so ranks shard them with no data-path collective
 (weak scaling: every rank processes --pairs pairs per step).
 """
 import argparse
-import ctypes as C
+import concurrent.futures
 import json
 import os
 import sys
@@ -24,31 +24,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (height, width, max_features, fixed_iters, default pairs per step)
-    "c2_640x480_2000kp": (480, 640, 2000, 0, 512),
-    "c3_kitti_1241x376_4000kp": (376, 1241, 4000, 0, 256),
-    "c5_1080p_10000kp_4096hyp": (1080, 1920, 10000, 4096, 32),
+    # the reference's own CPU-runnable case: a 101-frame directory walked pair by pair with
+    # orb_matcher{1000} (ref:src/main.cpp:144-184); one step = the 100 consecutive pairs
+    "c1_640x480_1000kp_seq100": dict(h=480, w=640, nfeat=1000, fixed=0, pairs=100, sequence=True),
+    "c2_640x480_2000kp": dict(h=480, w=640, nfeat=2000, fixed=0, pairs=512, sequence=False),
+    "c3_kitti_1241x376_4000kp": dict(h=376, w=1241, nfeat=4000, fixed=0, pairs=256, sequence=False),
+    "c5_1080p_10000kp_4096hyp": dict(h=1080, w=1920, nfeat=10000, fixed=4096, pairs=32, sequence=False),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# Ceilings (MI355X): HBM3E spec peak; vector ALUs: 256 CUs x 4 SIMDs x 32 lanes per clock at
+# 2.4 GHz = 7.86e13 lane-operations/s for 32-bit integer work, one fp64 FMA (2 flops) per lane
+# every other clock = 78.6 TFLOP/s.
+PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": (78.6, "TFLOP/s")}
+KERNEL_OF_GROUP = {
+    "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel", "select": "select_a + harris + select_b kernels",
+    "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_bcast_kernel",
+    "ratio": "ratio_kernel", "ransac_solve": "solve_front_kernel + solve_back_kernel", "ransac_score": "score_kernel",
+    "ransac_other": "normalize / init / update / finish kernels",
+}
+BOUND_OF_GROUP = {"resize": "hbm", "fast": "hbm", "select": "hbm", "blur": "hbm", "describe": "hbm", "knn2": "valu_int",
+                  "ratio": "hbm", "ransac_solve": "valu_fp64", "ransac_score": "valu_fp64", "ransac_other": "valu_fp64"}
+SAMPSON_FLOPS = 45.0          # fp64 operations of one (essential matrix, match) Sampson test
+FIVE_POINT_FLOPS = 3.0e4      # one five-point solve: null space, 10x20 elimination, degree-10 roots, polishing (estimate)
+KNN_LANE_OPS = 20.0           # per (query, train row): 8 xor + 8 popcount-accumulate + 4 for the top-2 update
 
 
-KERNEL_OF_GROUP = {"resize": "resize_kernel", "fast": "fast_kernel", "blur": "blur_kernel", "describe": "describe_kernel"}
-
-
-def algorithmic_bytes(h, w, n_images, max_features):
-    """Bytes each image kernel group has to move per launch group (one step), counted once:
-    resize reads level l-1 and writes level l; FAST reads every level pixel; the blur reads and
-    writes every level pixel; describe reads the 31x31 disc and the 37x37 blurred window of each
-    keypoint and writes 28 + 32 bytes."""
+def level_pixels(h, w):
     lv = []
     for l in range(8):
         s = np.float32(1.2) ** l
         lv.append(int(np.rint(np.float32(w) / np.float32(s))) * int(np.rint(np.float32(h) / np.float32(s))))
+    return lv
+
+
+def algorithmic_work(h, w, n_images, out, stats):
+    """Algorithmic bytes / lane-operations / flops of ONE step per kernel group, counted once:
+    resize reads level l-1 and writes level l; FAST reads every level pixel; the blur reads and
+    writes every level pixel; selection reads every FAST candidate twice (histogram, cut), an
+    81-byte Harris window per survivor of the first cut (at most 2 x max_features per image) and
+    writes the keypoints; describe reads the 31x31 disc and the 37x37 blurred window of each
+    keypoint and writes 28 + 32 bytes; the matcher compares every query row with every train
+    row of its pair; RANSAC tests every candidate model of the hypotheses the serial loop walks
+    on every match and solves one five-point problem per hypothesis."""
+    lv = level_pixels(h, w)
+    kps = float(np.sum(out["n_kp1"]) + np.sum(out["n_kp2"])) * n_images / (2.0 * len(out))
+    cands = stats["candidates"] / max(stats["calls"], 1)
     return {
         "resize": n_images * sum(lv[l - 1] + lv[l] for l in range(1, 8)),
         "fast": n_images * sum(lv),
+        "select": cands * 8 + min(cands, 2.0 * kps) * (81 + 8) + kps * 8,
         "blur": n_images * 2 * sum(lv),
-        "describe": n_images * max_features * (31 * 31 + 37 * 37 + 60),
+        "describe": kps * (31 * 31 + 37 * 37 + 60),
+        "knn2": KNN_LANE_OPS * float(np.sum(out["n_kp1"].astype(np.float64) * out["n_kp2"])),
+        "ratio": float(np.sum(out["n_kp1"])) * 16 + float(np.sum(out["n_matches"])) * 28,
+        "ransac_solve": FIVE_POINT_FLOPS * float(np.sum(out["ransac_iters"])),
+        "ransac_score": SAMPSON_FLOPS * float(np.sum(out["models_scored"].astype(np.float64) * out["n_matches"])),
     }
 
 
@@ -65,72 +94,199 @@ def measured_traffic(workload, pairs, group):
     return rec.get("bytes_per_launch", {}).get(group)
 
 
-def measured_valu(workload, pairs, kernel, launch_ms):
-    """Vector-ALU issue accounting of a kernel from the committed SQ counter passes: wavefront VALU
-    instructions per launch and the share of the GPU's issue slots they fill over the launch
-    duration measured in this run (a wave64 instruction holds one of 1024 SIMDs for four cycles
-    at 2.4 GHz; plain adds and logic ops in long runs issue faster, so the share is an upper
-    bound of the occupancy and a kernel at ~0.9 is issue-bound)."""
-    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
-    try:
-        rec = json.load(open(path))
-    except OSError:
-        return None
-    k = rec.get("kernels", {}).get(kernel)
-    if rec.get("workload") != workload or rec.get("pairs_per_step") != pairs or not k or "SQ_INSTS_VALU" not in k:
-        return None
-    slots = rec["simds"] * rec["clock_ghz"] * 1e9 * launch_ms * 1e-3 / 4.0
-    return {"wave_insts_per_launch": k["SQ_INSTS_VALU"], "issue_slots_per_launch": slots,
-            "frac": k["SQ_INSTS_VALU"] / slots}
+def _gen_pair(args):
+    from visual_odometry_amd import synth
+    seed, h, w, sparse = args
+    if sparse:
+        return synth.frame_pair(seed, height=h, width=w, sparse=True, moving_fraction=0.6, n_layers=24)
+    return synth.frame_pair(seed, height=h, width=w)
 
 
-def cpu_baseline(frames, K, max_features, fixed_iters, budget_s=12.0):
-    """The CPU oracle (scalar port of the reference path) on the same frames, one thread."""
+def make_frames(cfg, rank, n_distinct, sparse):
+    """Distinct synthetic frames of the workload: 2 * n_distinct for pair workloads (generated on
+    the host cores in parallel, before anything touches the GPU), pairs + 1 for a sequence."""
+    from visual_odometry_amd import synth
+    if cfg["sequence"]:
+        return synth.sequence(0x5EED0000 + 1000 * rank, cfg["pairs"] + 1, height=cfg["h"], width=cfg["w"])
+    jobs = [(0x5EED0000 + 100000 * rank + p, cfg["h"], cfg["w"], sparse) for p in range(n_distinct)]
+    workers = max(1, min(16, os.cpu_count() or 1, n_distinct))
+    if workers == 1:
+        pairs = [_gen_pair(j) for j in jobs]
+    else:
+        with concurrent.futures.ProcessPoolExecutor(workers) as pool:
+            pairs = list(pool.map(_gen_pair, jobs, chunksize=max(1, n_distinct // (4 * workers))))
+    return [f for ab in pairs for f in ab]
+
+
+def cpu_baseline(frames, K, cfg, budget_s=12.0):
+    """The CPU oracle (scalar port of the reference path) on a bounded sample of the same frames:
+    one thread, then one frame pair per thread on the box's CPU share.  Both of the reference's
+    definitions are reported: the whole pair (detect x2 + match + estimate_motion, what its main
+    loop does per pair) and ms per match_images call with estimate_motion outside the timed
+    region (ref:benchmarks/benchmark_matchers.cpp:111-135)."""
     from oracle import oracle as O
-    n_done, t0 = 0, time.perf_counter()
-    t_match_only = 0.0
-    n_pairs = len(frames) // 2
-    while time.perf_counter() - t0 < budget_s:
-        a, b = frames[2 * (n_done % n_pairs)], frames[2 * (n_done % n_pairs) + 1]
+    nfeat, fixed = cfg["nfeat"], cfg["fixed"]
+    if cfg["sequence"]:
+        pair_frames = [(frames[i], frames[i + 1]) for i in range(len(frames) - 1)]
+    else:
+        pair_frames = [(frames[2 * i], frames[2 * i + 1]) for i in range(len(frames) // 2)]
+    n_pairs = len(pair_frames)
+
+    def one_pair(i, times=None):
+        a, b = pair_frames[i % n_pairs]
         t1 = time.perf_counter()
-        ka, da = O.orb_detect(a, max_features)
-        kb, db = O.orb_detect(b, max_features)
+        ka, da = O.orb_detect(a, nfeat)
+        kb, db = O.orb_detect(b, nfeat)
         qi, ti, _ = O.match(da, db)
-        t_match_only += time.perf_counter() - t1
+        if times is not None:
+            times.append(time.perf_counter() - t1)
         p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
         p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
-        O.estimate_motion(p1, p2, K, fixed_iters=fixed_iters)
+        O.estimate_motion(p1, p2, K, fixed_iters=fixed)
+
+    n_done, t0, t_match = 0, time.perf_counter(), []
+    while time.perf_counter() - t0 < budget_s and (n_done < n_pairs or not cfg["sequence"]):
+        one_pair(n_done, t_match)
         n_done += 1
     dt = time.perf_counter() - t0
     out = {
         "value": n_done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-        "sample": f"{n_done} frame pairs drawn from the benchmark's {n_pairs} distinct pairs, detect x2 + match + E-RANSAC + pose, "
-                  f"{dt:.1f} s on one host thread (oracle/vo_oracle.cpp, g++ -O2)",
-        "ms_per_match_images": 1e3 * t_match_only / max(n_done, 1),
+        "sample": f"{n_done} of the workload's {n_pairs} distinct frame pairs, detect x2 + match + E-RANSAC + pose, "
+                  f"{dt:.1f} s on one host thread (oracle/vo_oracle.cpp, g++ -O2; every frame detected twice, as the "
+                  f"reference's loop does)",
+        "ms_per_pair": 1e3 * dt / max(n_done, 1),
+        "ms_per_match_images": 1e3 * float(np.sum(t_match)) / max(n_done, 1),
     }
-
-    # the same work over independent frame pairs on several host threads (the oracle is reached
-    # through ctypes, which releases the GIL); the box gives one GPU's share of 16 cores
-    import concurrent.futures
     threads = max(1, min(16, os.cpu_count() or 1))
-
-    def one_pair(i):
-        a, b = frames[2 * (i % n_pairs)], frames[2 * (i % n_pairs) + 1]
-        ka, da = O.orb_detect(a, max_features)
-        kb, db = O.orb_detect(b, max_features)
-        qi, ti, _ = O.match(da, db)
-        p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
-        p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
-        O.estimate_motion(p1, p2, K, fixed_iters=fixed_iters)
-
     per_thread = max(1, int(round(0.5 * budget_s * out["value"])))   # about half the budget again
     t0 = time.perf_counter()
-    with concurrent.futures.ThreadPoolExecutor(threads) as pool:
+    with concurrent.futures.ThreadPoolExecutor(threads) as pool:   # the oracle is reached through ctypes: no GIL
         list(pool.map(one_pair, range(threads * per_thread)))
     dt = time.perf_counter() - t0
     out["multi_thread"] = {"value": threads * per_thread / dt, "unit": "frame-pairs/s", "cores": threads,
                            "sample": f"{threads * per_thread} frame pairs on {threads} threads, {dt:.1f} s"}
     return out
+
+
+class Runner:
+    """One workload resident in HBM: its step function, the per-group profile and the timed region."""
+
+    def __init__(self, torch, dist, capi, ctxs, cfg, frames, P, K, world):
+        self.torch, self.dist, self.capi, self.ctxs, self.cfg, self.P, self.K, self.world = \
+            torch, dist, capi, ctxs, cfg, P, K, world
+        H, W = cfg["h"], cfg["w"]
+        if cfg["sequence"]:
+            self.n_images = P + 1
+            stack = np.stack(frames[: P + 1])
+        else:
+            n_distinct = len(frames) // 2
+            self.n_images = 2 * P
+            stack = np.stack([frames[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)])
+        self.imgs = torch.from_numpy(stack).cuda()
+        self.ress = [torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in ctxs]
+        self.counter = 0
+        self.H, self.W = H, W
+
+    def call(self, ctx, res):
+        c = self.cfg
+        fn = ctx.pipeline_sequence_dev if c["sequence"] else ctx.pipeline_pairs_dev
+        n = self.P + 1 if c["sequence"] else self.P
+        fn(self.imgs.data_ptr(), n, self.H, self.W, self.W, self.H * self.W, c["nfeat"], 0.75, self.K, 1.0, 0.999,
+           c["fixed"], res.data_ptr())
+
+    def step(self):
+        k = self.counter % len(self.ctxs)
+        self.counter += 1
+        self.call(self.ctxs[k], self.ress[k])
+
+    def fence(self):
+        for c in self.ctxs:
+            c.sync()
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def results(self, k=0):
+        return np.frombuffer(self.ress[k].cpu().numpy().tobytes(), self.capi.PAIR_DTYPE)
+
+    def profile(self, reps=3):
+        """Untimed pass: every kernel group bracketed by events, one stream, nothing overlapped.
+        Returns ms per step of each group (the RANSAC chain split into solve / score / rest in
+        a second pass, because the split brackets sit inside the chain's bracket) and the FAST
+        stage's scene counters."""
+        ctx, res, capi = self.ctxs[0], self.ress[0], self.capi
+        ctx.fast_stats(True)          # (the scene counters are global atomics: counted in a call of their own)
+        self.call(ctx, res)
+        ctx.sync()
+        stats = ctx.fast_stats(False)
+        stats["calls"] = 1
+        ctx.set_timing(True)
+        for _ in range(reps):
+            self.call(ctx, res)
+            ctx.sync()
+        ms = {}
+        for g, name in enumerate(capi.T_TOP):
+            t, n = ctx.kernel_time_ms(g)
+            ms[name] = t * n / reps if n else 0.0
+        ctx.set_timing(True, groups=["ransac_solve", "ransac_score"])
+        for _ in range(reps):
+            self.call(ctx, res)
+            ctx.sync()
+        for name in ("ransac_solve", "ransac_score"):
+            t, n = ctx.kernel_time_ms(capi.T_GROUPS.index(name))
+            ms[name] = t * n / reps if n else 0.0
+        ms["ransac_other"] = max(ms["ransac"] - ms["ransac_solve"] - ms["ransac_score"], 0.0)
+        ctx.set_timing(False)
+        return ms, stats
+
+    def timed(self, steps, group):
+        """Exactly `steps` steps between two fences; only `group` keeps its event brackets (a bracket
+        costs ~10 us of stream time).  Returns (seconds, mean launch ms of the group, launches)."""
+        torch, dist = self.torch, self.dist
+        gi = self.capi.T_GROUPS.index(group)
+        for c in self.ctxs:
+            c.set_timing(True, groups=[group])
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        dom = [c.kernel_time_ms(gi) for c in self.ctxs]
+        launches = sum(n for _, n in dom)
+        avg_ms = sum(ms * n for ms, n in dom if n > 0) / max(launches, 1)
+        for c in self.ctxs:
+            c.set_timing(False)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), avg_ms, launches
+
+
+def roofline_of(group, work_per_step, avg_ms, launches, steps, workload, P):
+    bound = BOUND_OF_GROUP[group]
+    peak, unit = PEAK[bound]
+    per_step = launches / max(steps, 1)
+    per_launch = work_per_step[group] / max(per_step, 1e-9)
+    scale = 1e9 if bound == "hbm" else 1e12
+    achieved = per_launch / max(avg_ms * 1e-3, 1e-12) / scale
+    what = {"hbm": "algorithmic_bytes_per_launch", "valu_int": "algorithmic_lane_ops_per_launch",
+            "valu_fp64": "algorithmic_flops_per_launch"}[bound]
+    return {"bound": bound, "kernel": KERNEL_OF_GROUP[group], "achieved": achieved, "peak": peak, "unit": unit,
+            "frac": achieved / peak, "traffic": measured_traffic(workload, P, group) if bound == "hbm" else None,
+            "avg_launch_ms": avg_ms, "launches_timed": launches, "launches_per_step": per_step, what: per_launch}
+
+
+def scene_stats(stats, out):
+    px = max(stats["pixels"], 1)
+    m = np.maximum(out["n_matches"], 1)
+    return {"pretest_pass_frac": stats["pretest_pass"] / px, "corner_frac": stats["corners"] / px,
+            "corners_per_Mpx": 1e6 * stats["corners"] / px, "candidates_after_nms_per_Mpx": 1e6 * stats["candidates"] / px,
+            "mean_keypoints": float(np.mean(out["n_kp1"])), "mean_matches": float(np.mean(out["n_matches"])),
+            "mean_inliers": float(np.mean(out["inliers"])), "mean_inlier_ratio": float(np.mean(out["inliers"] / m)),
+            "valid_fraction": float(np.mean(out["valid"])), "mean_ransac_iters": float(np.mean(out["ransac_iters"])),
+            "mean_models_per_hypothesis": float(np.sum(out["models_scored"]) / max(np.sum(out["ransac_iters"]), 1)),
+            "truncated_pairs": int(np.count_nonzero(out["status"]))}
 
 
 def main():
@@ -140,139 +296,115 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2_640x480_2000kp", choices=list(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per step per GPU")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs (tiled up to --pairs)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic pairs, tiled up to --pairs (default: all pairs distinct)")
+    ap.add_argument("--scene", default="dense", choices=["dense", "sparse"],
+                    help="dense: every level over-fills its keypoint quota many times, ~70 %% inliers; sparse: a few "
+                         "corners per thousand pixels, layers that move on their own (~40 %% inliers)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (streams + workspace) the steps rotate over; one context already "
                          "overlaps a batch's RANSAC rounds (side stream) with the next batch's detection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-sequence", action="store_true")
+    ap.add_argument("--no-aux-scene", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
     args = ap.parse_args()
-
-    import torch   # before the HIP library: one HIP runtime for both
-    import torch.distributed as dist
-    from visual_odometry_amd import capi, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    cfg = WORKLOADS[args.workload]
+    H, W, nfeat, fixed = cfg["h"], cfg["w"], cfg["nfeat"], cfg["fixed"]
+    P = cfg["pairs"] if cfg["sequence"] else (args.pairs or cfg["pairs"])
+    n_distinct = P if cfg["sequence"] else max(1, min(args.distinct or P, P))
+    # synthetic frames first (worker processes), the GPU runtime afterwards
+    frames = make_frames(cfg, rank, n_distinct, args.scene == "sparse")
+    aux_frames = None
+    if not args.no_aux_scene and not cfg["sequence"] and args.scene == "dense":
+        aux_frames = make_frames(cfg, rank, min(64, P), True)
+
+    import torch   # before the HIP library: one HIP runtime for both
+    import torch.distributed as dist
+    from visual_odometry_amd import capi, sharding, synth
+
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    H, W, nfeat, fixed, default_pairs = WORKLOADS[args.workload]
-    P = args.pairs or default_pairs
     K = synth.default_K(W, H)
-    n_distinct = max(1, min(args.distinct, P))
-    frames = []
-    for p in range(n_distinct):
-        a, b = synth.frame_pair(0x5EED0000 + 1000 * rank + p, height=H, width=W)
-        frames += [a, b]
-    tiled = [frames[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)]
-    imgs = torch.from_numpy(np.stack(tiled)).cuda()
     n_streams = max(1, args.streams)
     ctxs = [capi.Context(local_rank) for _ in range(n_streams)]
-    ress = [torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(n_streams)]
-    ctx, res = ctxs[0], ress[0]
-    counter = [0]
-
-    def step():
-        k = counter[0] % n_streams
-        counter[0] += 1
-        ctxs[k].pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
-                                   ress[k].data_ptr())
-
-    def fence():
-        for c in ctxs:
-            c.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    ctx = ctxs[0]
+    run = Runner(torch, dist, capi, ctxs, cfg, frames, P, K, world)
 
     for _ in range(max(args.warmup, n_streams)):
-        step()
-    fence()
+        run.step()
+    run.fence()
+    kernel_ms, stats = run.profile()
+    out = run.results()
+    work = algorithmic_work(H, W, run.n_images, out, stats)
+    dominant = max(work, key=lambda g: kernel_ms[g])
+    dt, dom_avg_ms, dom_launches = run.timed(args.steps, dominant)
+    out = run.results()
+    value = P * args.steps * world / dt
 
-    # Untimed profile pass: every kernel group bracketed by events, one stream, to find the
-    # dominant kernel and to report the per-group times.
-    ctx.set_timing(True)
-    for _ in range(3):
-        ctx.pipeline_pairs_dev(imgs.data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed, res.data_ptr())
-        ctx.sync()   # no overlap between calls here: every group is timed on an otherwise idle GPU
-    # a group may bracket more than one launch per call (FAST: level 0 and the upper levels)
-    kernel_ms = {}
-    for g, name in enumerate(capi.T_GROUPS):
-        ms, n = ctx.kernel_time_ms(g)
-        kernel_ms[name] = ms * n / 3.0
-    alg_bytes = algorithmic_bytes(H, W, 2 * P, nfeat)
-    dominant = max(alg_bytes, key=lambda g: kernel_ms[g])
-
-    # Timed region: only the dominant kernel keeps its event brackets (a bracket costs ~10 us of
-    # stream time); its average launch duration over exactly these steps feeds the roofline.
-    for c in ctxs:
-        c.set_timing(True, groups=[dominant])
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    dom = [c.kernel_time_ms(capi.T_GROUPS.index(dominant)) for c in ctxs]
-    dom_launches = sum(n for _, n in dom)
-    dom_avg_ms = sum(ms * n for ms, n in dom if n > 0) / max(dom_launches, 1)
-    for c in ctxs:
-        c.set_timing(False)
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
-    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
-    total_pairs = P * args.steps * world
-    value = total_pairs / dt
-
-    launches_per_step = dom_launches / max(args.steps, 1)
-    dom_bytes = alg_bytes[dominant] / max(launches_per_step, 1e-9)   # algorithmic bytes of an average launch
-    achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9
     line = {
         "metric": "frame-pairs/sec (ORB+match+E-RANSAC, 640x480, 2k kps) + Hamming match GB/s",
         "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": args.workload, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct,
+                   "scene": args.scene, "mode": "consecutive frames of a sequence, each detected once"
+                   if cfg["sequence"] else "independent pairs, both images of every pair detected",
                    "image": f"{W}x{H}", "max_features": nfeat, "ratio": 0.75,
                    "ransac": "adaptive<=1000" if fixed == 0 else f"fixed {fixed}", "parallelism": f"pairs x{world}",
                    "streams_per_gpu": n_streams},
-        "roofline": {"bound": "hbm", "kernel": KERNEL_OF_GROUP[dominant], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(args.workload, P, dominant),
-                     "valu": measured_valu(args.workload, P, KERNEL_OF_GROUP[dominant], dom_avg_ms),
-                     "avg_launch_ms": dom_avg_ms, "launches_timed": dom_launches,
-                     "launches_per_step": launches_per_step,
-                     "algorithmic_bytes_per_launch": dom_bytes,
-                     "note": "achieved = algorithmic bytes per launch / mean launch duration by HIP events on the "
-                             "kernel's stream inside the timed steps (with more than one stream the duration "
-                             "includes what the neighbour stream's kernels take from the GPU); traffic = "
-                             "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the configuration matches; "
-                             "valu = the kernel's wavefront VALU instructions per launch (SQ_INSTS_VALU, "
-                             "profiles/) against the vector-ALU issue slots of the launch: the ceiling that "
-                             "binds this kernel, the HBM fraction being what the contract asks for"},
-        "pipeline": {"mean_keypoints": float(np.mean(out["n_kp1"])), "mean_matches": float(np.mean(out["n_matches"])),
-                     "mean_inliers": float(np.mean(out["inliers"])), "valid_fraction": float(np.mean(out["valid"])),
-                     "mean_ransac_iters": float(np.mean(out["ransac_iters"])),
-                     "kernel_group_ms_per_step_single_stream": kernel_ms,
-                     "algorithmic_GBps_single_stream": {g: alg_bytes[g] / (kernel_ms[g] * 1e-3) / 1e9 for g in alg_bytes}},
+        "roofline": roofline_of(dominant, work, dom_avg_ms, dom_launches, args.steps, args.workload, P),
+        "scene": scene_stats(stats, out),
+        "pipeline": {"kernel_group_ms_per_step_single_stream": kernel_ms,
+                     "algorithmic_work_per_step": work,
+                     "fraction_of_group_ceiling_single_stream": {
+                         g: work[g] / (kernel_ms[g] * 1e-3) / (1e9 if BOUND_OF_GROUP[g] == "hbm" else 1e12) /
+                         PEAK[BOUND_OF_GROUP[g]][0] for g in work if kernel_ms[g] > 0}},
     }
+    line["roofline"]["note"] = (
+        "the kernel group with the largest time per step among all groups, against that group's own ceiling: HBM "
+        "bytes for the image kernels, 32-bit vector-ALU lane-operations (20 per query x train row) for the matcher, "
+        "fp64 vector flops (45 per model x match Sampson test, ~3e4 per five-point solve) for the RANSAC kernels; "
+        "achieved = algorithmic work of an average launch / mean launch duration by HIP events on the kernel's "
+        "stream inside the timed steps; traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the "
+        "configuration matches")
 
-    if not args.no_sequence:
+    if aux_frames is not None:
+        # The other end of the scene range: few corners, ~40 % inliers (many RANSAC rounds).  Short
+        # run, same code path; not the headline.
+        aux = Runner(torch, dist, capi, ctxs, cfg, aux_frames, P, K, world)
+        for _ in range(2):
+            aux.step()
+        aux.fence()
+        a_ms, a_stats = aux.profile()
+        a_out = aux.results()
+        a_work = algorithmic_work(H, W, aux.n_images, a_out, a_stats)
+        a_dom = max(a_work, key=lambda g: a_ms[g])
+        a_steps = max(3, args.steps // 4)
+        a_dt, a_avg, a_n = aux.timed(a_steps, a_dom)
+        line["aux_sparse_scene"] = {
+            "value": P * a_steps * world / a_dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * a_dt / a_steps,
+            "steps": a_steps, "distinct_pairs": len(aux_frames) // 2,
+            "roofline": roofline_of(a_dom, a_work, a_avg, a_n, a_steps, args.workload + "/sparse", P),
+            "fast_kernel_fraction_of_hbm_single_stream": a_work["fast"] / (a_ms["fast"] * 1e-3) / 1e9 / PEAK["hbm"][0],
+            "scene": scene_stats(a_stats, a_out), "kernel_group_ms_per_step_single_stream": a_ms}
+        del aux
+
+    if not args.no_sequence and not cfg["sequence"]:
         # the same pipeline fed as a video sequence: 2P consecutive frames -> 2P - 1 pairs, each
         # frame detected once (what a streaming caller of the reference's main loop would use).
-        # 2P frames, so that the detection launches have the size of the headline steps' and the
-        # per-kernel averages of a profile of this command are not mixed from two launch sizes.
-        # (synthetic sequence: the two frames of the first pair alternate, so that every
-        # consecutive pair shows the same scene under a small motion)
+        # 2P frames, so that the detection launches have the size of the headline steps'.
+        # (the two frames of the first pair alternate, so that every consecutive pair shows the
+        # same scene under a small motion)
         F = 2 * P
         seq = torch.from_numpy(np.stack([frames[i & 1] for i in range(F)])).cuda()
         res_seq = torch.zeros((F - 1) * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -280,12 +412,12 @@ def main():
         for _ in range(2):
             ctx.pipeline_sequence_dev(seq.data_ptr(), F, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
                                       res_seq.data_ptr())
-        fence()
+        run.fence()
         t0 = time.perf_counter()
         for _ in range(reps):
             ctx.pipeline_sequence_dev(seq.data_ptr(), F, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
                                       res_seq.data_ptr())
-        fence()
+        run.fence()
         sd = (time.perf_counter() - t0) / reps
         t = torch.tensor([sd], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -295,45 +427,78 @@ def main():
                                  "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
                                  "note": "consecutive frames, every frame detected once (vo_pipeline_sequence_dev); "
                                          "not the headline metric, which detects both images of every pair"}
+        del seq, res_seq
 
     if not args.no_hamming:
-        # second half of the metric: brute-force Hamming kNN(2), 65 536 x 65 536 descriptors
-        # (query rows sharded over ranks, train set replicated, results gathered on rank 0)
+        # second half of the metric: brute-force Hamming kNN(2), 65 536 x 65 536 descriptors.  Query
+        # rows are sharded over the ranks in contiguous blocks (sharding.block_range), the train set
+        # is replicated, and every repetition ends with the path's one collective: the ranks'
+        # (idx2 | dist2) rows gathered on rank 0 (sharding.sharded_knn2, the function the
+        # world_size-2 CPU test drives).
         nq_total, nt = 65536, 65536
-        nq = nq_total // world
-        q = torch.from_numpy(synth.descriptors(7, nq_total)[rank * nq:(rank + 1) * nq]).cuda()
+        b, e = sharding.block_range(nq_total, rank, world)
+        q_all = torch.from_numpy(synth.descriptors(7, nq_total)).cuda()
         tr = torch.from_numpy(synth.descriptors(8, nt)).cuda()
-        idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
-        dst = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+        idx = torch.empty((e - b, 2), dtype=torch.int32, device="cuda")
+        dst = torch.empty((e - b, 2), dtype=torch.int32, device="cuda")
+
+        def gpu_knn2(q_rows, t_rows):
+            ctx.hamming_knn2_dev(q_rows.data_ptr(), q_rows.shape[0], t_rows.data_ptr(), t_rows.shape[0],
+                                 idx.data_ptr(), dst.data_ptr())
+            ctx.sync()
+            return idx, dst
+
         for _ in range(2):
-            ctx.hamming_knn2_dev(q.data_ptr(), nq, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
-        fence()
+            table = sharding.sharded_knn2(gpu_knn2, q_all, tr)
+        run.fence()
         reps = 5
         ctx.set_timing(True, groups=["knn2"])
         t0 = time.perf_counter()
         for _ in range(reps):
-            ctx.hamming_knn2_dev(q.data_ptr(), nq, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
-        ctx.sync()
-        if world > 1:
-            gathered = [torch.empty_like(idx) for _ in range(world)] if rank == 0 else None
-            dist.gather(idx, gathered, dst=0)     # the one collective: matches to rank 0
-        fence()
+            table = sharding.sharded_knn2(gpu_knn2, q_all, tr)   # kernel + (world > 1) the gather, every repetition
+        run.fence()
         hd = (time.perf_counter() - t0) / reps
         t = torch.tensor([hd], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         hd = float(t.item())
+        k_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
+        ctx.set_timing(False)
         alg_bytes = float(nq_total) * nt * 32
+        lane_ops = KNN_LANE_OPS * nq_total * nt
         line["hamming"] = {"workload": "c4_hamming_65536x65536", "value": alg_bytes / hd / 1e9,
                            "unit": "GB/s (Nq*Nt*32 B / s)", "pair_compares_per_s": float(nq_total) * nt / hd,
-                           "ms": 1e3 * hd, "kernel_ms_rank0": ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0],
-                           # 16 xor/popcount ops + 1 compare per pair; the 3-op top-2 update runs
-                           # only for row groups that can improve some lane (rare at this size)
-                           "lane_ops_per_s": 17.0 * nq_total * nt / hd,
+                           "ms": 1e3 * hd, "kernel_ms_rank0": k_ms, "rows_this_rank": e - b,
+                           "table_rows_on_rank0": int(table.shape[0]) if table is not None else None,
+                           "roofline": {"bound": "valu_int", "kernel": "knn2_bcast_kernel",
+                                        "achieved": lane_ops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 * world,
+                                        "peak": PEAK["valu_int"][0] * world, "unit": "Tlane-op/s",
+                                        "frac": lane_ops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 / PEAK["valu_int"][0],
+                                        "traffic": None,
+                                        "note": "20 lane-operations per query x train row against 32 lanes per clock "
+                                                "and SIMD; v_bcnt and every xor with a non-register operand issue at "
+                                                "half that rate, which caps this instruction mix near 0.55"},
                            "compulsory_hbm_bytes": (nq_total + nt) * 32 + nq_total * 16}
+        del q_all, tr
+
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # The reference benchmark's own metric on the GPU path: wall-clock ms per match_images call
+        # (host images in, matched points out, estimate_motion excluded) through the fused
+        # host-buffer entry point the C++ drop-in's match_images_orb uses.
+        if hasattr(ctx, "match_images"):
+            if cfg["sequence"]:
+                pf = [(frames[i], frames[i + 1]) for i in range(min(20, len(frames) - 1))]
+            else:
+                pf = [(frames[2 * i], frames[2 * i + 1]) for i in range(min(20, len(frames) // 2))]
+            for a, b_ in pf[:3]:
+                ctx.match_images(a, b_, nfeat, 0.75)
+            t0 = time.perf_counter()
+            for a, b_ in pf:
+                ctx.match_images(a, b_, nfeat, 0.75)
+            line["dropin_ms_per_match_images"] = 1e3 * (time.perf_counter() - t0) / len(pf)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(frames, K, nfeat, fixed)
+        line["cpu_baseline"] = cpu_baseline(frames, K, cfg)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -46,7 +46,7 @@ typedef struct vo_pair_result {
     int32_t n_matches;
     int32_t ransac_iters;
     int32_t status;   /* VO_TRUNC_* bits of the pair's two images; 0 = complete */
-    int32_t reserved;
+    int32_t models_scored; /* essential-matrix candidates of the ransac_iters hypotheses (each is tested on every match) */
 } vo_pair_result;
 
 /* A keypoint list of an image did not fit an internal table or the caller's
@@ -107,8 +107,12 @@ enum {
     VO_T_KNN2 = 5,     /* Hamming top-2 */
     VO_T_RATIO = 6,    /* ratio test + compaction */
     VO_T_RANSAC = 7,   /* all RANSAC and pose kernels of one call */
-    VO_T_COUNT = 8,
-    VO_T_ALL = (1 << 8) - 1
+    /* inside the RANSAC chain, per round (selecting one of these splits the chain's bracket;
+     * do not combine them with VO_T_RANSAC in one measurement): */
+    VO_T_RANSAC_SOLVE = 8, /* five-point solves: solve_front + solve_back */
+    VO_T_RANSAC_SCORE = 9, /* Sampson scoring of every (hypothesis, model) over the points */
+    VO_T_COUNT = 10,
+    VO_T_ALL = (1 << 8) - 1 /* the eight top-level groups */
 };
 int vo_set_timing(vo_ctx* ctx, int groups);
 float vo_kernel_time_ms(vo_ctx* ctx, int group, int* launches);
@@ -226,12 +230,22 @@ int vo_pipeline_sequence(vo_ctx* ctx, const uint8_t* imgs, int n_frames, int row
 /* --- inspection (parity tests) ---------------------------------------------------
  * Copies pyramid level `level` of image `image` of the most recent detect call
  * (blurred != 0: the 7x7 Gaussian-blurred copy the descriptors sample) to
- * host memory, tightly packed w x h. */
-int vo_debug_level(vo_ctx* ctx, int image, int level, int blurred, uint8_t* out, int* w, int* h);
+ * host memory, tightly packed w x h.  `out` holds out_bytes bytes: when that is
+ * less than w * h, nothing is copied, *w and *h are still set and the call
+ * returns VO_ERR_CAPACITY (out_bytes = 0 asks for the size). */
+int vo_debug_level(vo_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t out_bytes, int* w, int* h);
 /* FAST candidates (after non-max suppression and the 31-pixel border filter)
  * of one level of the most recent detect call as (x, y, score) triples, in no
  * particular order.  Returns the count in *n_out. */
 int vo_debug_candidates(vo_ctx* ctx, int image, int level, int32_t* out, int cap, int* n_out);
+/* Scene statistics of the FAST stage, for reporting what a benchmark scene looks
+ * like: enable != 0 zeroes the counters and makes every following detection add
+ * to them; enable == 0 waits for the streams, stops counting and returns
+ * out[0] = pixels tested (the 31-px interior of every level, plus the 1-px ring whose
+ * scores the non-max suppression needs), out[1] = pixels passing the four-cardinal
+ * pre-test, out[2] = FAST-9 corners, out[3] = candidates left after non-max suppression
+ * and the border filter. */
+int vo_debug_fast_stats(vo_ctx* ctx, int enable, uint64_t out[4]);
 
 /* The five-point minimal solver alone: `count` sets of 5 correspondences in
  * normalised image coordinates (x1, x2: count x 5 x 2 doubles).  Es receives

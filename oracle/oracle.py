@@ -108,6 +108,12 @@ def match(q, t, ratio=0.75):
     return qi[:m].copy(), ti[:m].copy(), d[:m].copy()
 
 
+def set_five_point_charts(n):
+    """Null-space charts the minimal solver is run in (default 4: complete solution sets for
+    parity checks; 1: OpenCV's single chart, for timing the CPU baseline)."""
+    lib().oracle_set_five_point_charts(int(n))
+
+
 def five_point(x1, x2):
     x1 = np.ascontiguousarray(x1, np.float64).reshape(5, 2)
     x2 = np.ascontiguousarray(x2, np.float64).reshape(5, 2)

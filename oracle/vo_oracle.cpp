@@ -732,9 +732,10 @@ void essential_constraints_dir(const double* E, const double* D, double* df) {
 // residual of the unit-norm result.
 double polish_model(const double* const B[4], double* xyz, double* Eout) {
     double E[9];
-    for (int it = 0; it <= 4; ++it) {
+    const int kSteps = 12;
+    for (int it = 0; it <= kSteps; ++it) {
         for (int k = 0; k < 9; ++k) E[k] = B[0][k] * xyz[0] + B[1][k] * xyz[1] + B[2][k] * xyz[2] + B[3][k];
-        if (it == 4) break;
+        if (it == kSteps) break;
         double f[10], J[3][10];
         essential_constraints(E, f);
         for (int c = 0; c < 3; ++c) essential_constraints_dir(E, B[c], J[c]);
@@ -761,6 +762,9 @@ double polish_model(const double* const B[4], double* xyz, double* Eout) {
         double d2 = (N[0][0] * (N[1][1] * g[2] - g[1] * N[2][1]) - N[0][1] * (N[1][0] * g[2] - g[1] * N[2][0]) +
                      g[0] * (N[1][0] * N[2][1] - N[1][1] * N[2][0])) * inv;
         xyz[0] -= d0; xyz[1] -= d1; xyz[2] -= d2;
+        // converged: one more pass only rebuilds E from the final (x,y,z)
+        double big = std::max(1.0, std::max(std::fabs(xyz[0]), std::max(std::fabs(xyz[1]), std::fabs(xyz[2]))));
+        if (std::max(std::fabs(d0), std::max(std::fabs(d1), std::fabs(d2))) <= 1e-14 * big) it = kSteps - 1;
     }
     double nrm = 0;
     for (int k = 0; k < 9; ++k) nrm += E[k] * E[k];
@@ -773,9 +777,13 @@ double polish_model(const double* const B[4], double* xyz, double* Eout) {
     return r;
 }
 
-// EMEstimatorCallback::runKernel: x1,x2 are 5 normalised points (x,y).
-// Writes up to 10 essential matrices (row-major 3x3, unit Frobenius norm).
-int five_point(const double* x1, const double* x2, double* Es, double* dbg = nullptr) {
+// EMEstimatorCallback::runKernel in ONE chart of the null space: x1,x2 are 5 normalised
+// points (x,y).  Writes up to 10 essential matrices (row-major 3x3, unit Frobenius norm).
+// chart 0 is OpenCV's: E = x*E0 + y*E1 + z*E2 + E3 on the null-space basis as the SVD
+// returns it.  chart k > 0 first reflects that basis by a fixed orthogonal 4x4 matrix
+// (I - 2 u u^T): the solutions are the same matrices, but the 10x10 elimination and the
+// hidden-variable polynomial are conditioned differently.
+int five_point_chart(const double* x1, const double* x2, int chart, double* Es, double* dbg = nullptr) {
     // Q (5 x 9): rows x2^T E x1 = 0 in the order [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]
     double Qt[9 * 5];  // Q transposed, 9 x 5
     for (int i = 0; i < 5; ++i) {
@@ -789,6 +797,17 @@ int five_point(const double* x1, const double* x2, double* Es, double* dbg = nul
     for (int j = 0; j < 5; ++j)
         for (int k = 0; k < 9; ++k) B.push_back(U[k * 5 + j]);
     complete_basis(B, 9, 5);
+    if (chart > 0) {
+        static const double U[3][4] = {{0.5, 0.5, 0.5, 0.5},
+                                       {0.1825741858350554, -0.3651483716701107, 0.5477225575051661, -0.7302967433402214},
+                                       {0.6708203932499369, 0.2236067977499790, -0.6708203932499369, 0.2236067977499790}};
+        const double* u = U[(chart - 1) % 3];
+        for (int k = 0; k < 9; ++k) {
+            double dot = 0;
+            for (int t = 0; t < 4; ++t) dot += u[t] * B[(5 + t) * 9 + k];
+            for (int t = 0; t < 4; ++t) B[(5 + t) * 9 + k] -= 2.0 * u[t] * dot;
+        }
+    }
     const double* EE[4] = {&B[5 * 9], &B[6 * 9], &B[7 * 9], &B[8 * 9]};  // null space
 
     // E(x,y,z) = x*E0 + y*E1 + z*E2 + E3, entries as polynomials
@@ -902,7 +921,7 @@ int five_point(const double* x1, const double* x2, double* Es, double* dbg = nul
         double xyz[3] = {xy1[0] / xy1[2], xy1[1] / xy1[2], z1};
         double Ev[9];
         double res = polish_model(EE, xyz, Ev);
-        if (!(res <= 1e-9)) continue;          // did not settle on a solution
+        if (!(res <= 1e-12)) continue;         // did not settle on a solution
         bool dup = false;                      // two starts that settled on the same solution
         for (int m = 0; m < count && !dup; ++m) {
             double dp = 0, dm = 0;
@@ -916,6 +935,38 @@ int five_point(const double* x1, const double* x2, double* Es, double* dbg = nul
         for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k];
         ++count;
         if (count == 10) break;
+    }
+    return count;
+}
+
+// Number of null-space charts the minimal solver is run in (1 = OpenCV's own chart only).
+// One chart loses true solutions on a few percent of the minimal samples of hard scenes:
+// when its 10x10 elimination is ill-conditioned the hidden-variable polynomial is wrong and
+// real roots go missing or land too far from a solution for the refinement.  OpenCV loses them
+// too, in a way that depends on its exact arithmetic; what any two correct solvers can agree
+// on is the complete solution set, so the checker takes the union over several charts
+// (duplicates dropped).  The CPU-baseline timing sets this to 1 to keep OpenCV's cost.
+static int g_five_point_charts = 4;
+
+int five_point(const double* x1, const double* x2, double* Es, double* dbg = nullptr) {
+    int count = five_point_chart(x1, x2, 0, Es, dbg);
+    for (int c = 1; c < g_five_point_charts && count < 10; ++c) {
+        double more[90];
+        int n = five_point_chart(x1, x2, c, more);
+        for (int i = 0; i < n && count < 10; ++i) {
+            bool dup = false;
+            for (int m = 0; m < count && !dup; ++m) {
+                double dp = 0, dm = 0;
+                for (int k = 0; k < 9; ++k) {
+                    dp = std::max(dp, std::fabs(Es[m * 9 + k] - more[i * 9 + k]));
+                    dm = std::max(dm, std::fabs(Es[m * 9 + k] + more[i * 9 + k]));
+                }
+                dup = std::min(dp, dm) < 1e-7;
+            }
+            if (dup) continue;
+            for (int k = 0; k < 9; ++k) Es[count * 9 + k] = more[i * 9 + k];
+            ++count;
+        }
     }
     return count;
 }
@@ -1183,6 +1234,7 @@ int oracle_match(const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio
 }
 
 int oracle_five_point(const double* x1, const double* x2, double* Es) { return five_point(x1, x2, Es); }
+void oracle_set_five_point_charts(int n) { g_five_point_charts = n < 1 ? 1 : n; }
 
 // Same, also returning the degree-10 polynomial (dbg[0..10], ascending), the raw
 // Durand-Kerner roots (dbg[11..30] as re,im pairs) and their number (dbg[31]).

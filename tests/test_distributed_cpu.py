@@ -26,10 +26,13 @@ def _worker(rank, world, port, nq, nt, out_path):
     from oracle import oracle as O
     q = synth.descriptors(7, nq, dup_fraction=0.1)
     t = synth.descriptors(8, nt, dup_fraction=0.1)
-    b, e = sharding.block_range(nq, rank, world)
-    idx, d = O.knn2(q[b:e], t)                       # the rank's shard of the distance matrix
-    both = torch.from_numpy(np.concatenate([idx, d], 1))
-    full = sharding.gather_rows(both, nq, dst=0)
+
+    def cpu_knn2(q_rows, t_rows):                    # the rank's shard of the distance matrix
+        idx, d = O.knn2(q_rows.numpy(), t_rows.numpy())
+        return torch.from_numpy(idx), torch.from_numpy(d)
+
+    # the function bench.py's Hamming leg calls, with the oracle in place of the GPU kernel
+    full = sharding.sharded_knn2(cpu_knn2, torch.from_numpy(q), torch.from_numpy(t), dst=0)
     if rank == 0:
         np.save(out_path, full.numpy())
     else:

@@ -71,6 +71,52 @@ def test_knn2_beyond_65536_train_rows(ctx, oracle):
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
 
 
+def test_c4_full_size_65536x65536(ctx, oracle):
+    """The 65 536 x 65 536 match of the benchmark at full size through vo_hamming_knn2_dev with
+    the dispatch the library picks, once whole and once as two 32 768-row query shards (what
+    two ranks would run).  More than 2 000 sampled query rows - the first and last row of 64-row
+    blocks, the whole last block, rows with planted exact duplicates at the first, middle and
+    last train rows - are checked against the oracle on the full train set; the two runs must
+    agree on every row."""
+    import torch
+    nq = nt = 65536
+    q = synth.descriptors(7, nq)
+    t = synth.descriptors(8, nt)
+    planted = np.array([0, 63, 64, 4097, 32767, 32768, 50000, 65472, 65535])
+    t[0] = q[planted[0]]                       # a distance-0 pair at both ends of the train set: ties -> (0, 65535)
+    t[65535] = q[planted[0]]
+    t[32767] = q[planted[4]]
+    t[32768] = q[planted[4]]
+    for k, r in enumerate(planted[1:4]):
+        t[1000 + k] = q[r]
+    t[65534] = q[planted[8]]
+    t[1] = q[planted[8]]
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+
+    def run(rows):
+        idx = torch.full((len(rows), 2), -7, dtype=torch.int32, device="cuda")
+        dst = torch.full((len(rows), 2), -7, dtype=torch.int32, device="cuda")
+        part = dq[rows[0]: rows[-1] + 1]
+        ctx.hamming_knn2_dev(part.data_ptr(), len(rows), dt.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+        ctx.sync()
+        return idx.cpu().numpy(), dst.cpu().numpy()
+
+    gi, gd = run(np.arange(nq))
+    a = run(np.arange(0, nq // 2))
+    b = run(np.arange(nq // 2, nq))
+    assert np.array_equal(np.concatenate([a[0], b[0]]), gi) and np.array_equal(np.concatenate([a[1], b[1]]), gd)
+    rng = np.random.default_rng(3)
+    blocks = rng.choice(nq // 64, 600, replace=False)
+    rows = np.unique(np.concatenate([blocks * 64, blocks * 64 + 63, np.arange(nq - 64, nq), planted,
+                                     rng.integers(0, nq, 900)]))
+    assert len(rows) >= 2048
+    oi, od = oracle.knn2(q[rows], t)
+    assert np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od)
+    assert list(gi[planted[0]]) == [0, 65535] and list(gd[planted[0]]) == [0, 0]
+    assert list(gi[planted[4]]) == [32767, 32768]
+    assert list(gi[planted[8]]) == [1, 65534]
+
+
 @pytest.mark.parametrize("ratio", [0.5, 0.75, 0.9])
 def test_match_ratio_matches_oracle(ctx, oracle, ratio):
     q = synth.descriptors(41, 1800, dup_fraction=0.05)
@@ -394,6 +440,65 @@ def test_kitti_shape_pipeline_pair(ctx, oracle):
     assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi))
     assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"]
     assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4
+
+
+def test_full_hd_fused_pipeline_fixed_4096_hypotheses(ctx, oracle):
+    """The 1080p / 10 000-keypoint / fixed-4096-hypothesis configuration through the fused
+    device-resident pipeline (two pairs), records against the oracle."""
+    import torch
+    from visual_odometry_amd import capi
+    K = synth.default_K(1920, 1080)
+    frames = list(synth.frame_pair(63, height=1080, width=1920)) + list(synth.frame_pair(64, height=1080, width=1920))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    res = torch.zeros(2 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_pairs_dev(imgs.data_ptr(), 2, 1080, 1920, 1920, 1080 * 1920, 10000, 0.75, K, 1.0, 0.999, 4096,
+                           res.data_ptr())
+    ctx.sync()
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    for p in range(2):
+        ka, da = oracle.orb_detect(frames[2 * p], 10000)
+        kb, db = oracle.orb_detect(frames[2 * p + 1], 10000)
+        qi, ti, _ = oracle.match(da, db)
+        o = oracle.estimate_motion(np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1),
+                                   K, fixed_iters=4096)
+        r = out[p]
+        assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi))
+        assert r["ransac_iters"] == 4096 and r["status"] == 0
+        assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"]
+        assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4
+
+
+def test_c1_sequence_of_101_frames_1000_keypoints(ctx, oracle):
+    """The reference's own CPU-runnable configuration (640x480, orb_matcher{1000}, 100 consecutive
+    pairs of a directory, TUM intrinsics; ref:src/main.cpp:144-184) on the synthetic 101-frame
+    sequence the benchmark's c1 workload uses, through vo_pipeline_sequence_dev: every fifth
+    pair's record against the oracle (which detects each frame on its own, as the reference does)."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = synth.sequence(0x5EED0000, 101)
+    seq = torch.from_numpy(np.stack(frames)).cuda()
+    res = torch.zeros(100 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_sequence_dev(seq.data_ptr(), 101, 480, 640, 640, 480 * 640, 1000, 0.75, TUM_K, 1.0, 0.999, 0,
+                              res.data_ptr())
+    ctx.sync()
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    assert out["valid"].mean() > 0.9 and (out["status"] == 0).all()
+    det = {}
+
+    def detect(i):
+        if i not in det:
+            det[i] = oracle.orb_detect(frames[i], 1000)
+        return det[i]
+
+    for p in list(range(0, 100, 5)) + [99]:
+        (ka, da), (kb, db) = detect(p), detect(p + 1)
+        qi, ti, _ = oracle.match(da, db)
+        o = oracle.estimate_motion(np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1), TUM_K)
+        r = out[p]
+        assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi)), p
+        assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"], p
+        if o["valid"]:
+            assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4, p
 
 
 # ------------------------------------------------------------------ fused pipeline

@@ -18,18 +18,20 @@ KP_DTYPE = np.dtype(
 PAIR_DTYPE = np.dtype(
     [("R", "<f8", (9,)), ("t", "<f8", (3,)), ("inliers", "<i4"), ("valid", "<i4"),
      ("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_matches", "<i4"), ("ransac_iters", "<i4"),
-     ("status", "<i4"), ("reserved", "<i4")]
+     ("status", "<i4"), ("models_scored", "<i4")]
 )
 
 EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
-    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_five_point",
+    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
-T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac"]
+T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac",
+            "ransac_solve", "ransac_score"]          # the last two split the RANSAC chain per round
+T_TOP = T_GROUPS[:8]
 
 _lib = None
 
@@ -76,8 +78,9 @@ def load():
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
-    lib.vo_debug_level.argtypes = [vp, i, i, i, vp, C.POINTER(i), C.POINTER(i)]
+    lib.vo_debug_level.argtypes = [vp, i, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
+    lib.vo_debug_fast_stats.argtypes = [vp, i, vp]
     lib.vo_debug_five_point.argtypes = [vp, vp, vp, i, vp, vp]
     _lib = lib
     return lib
@@ -125,7 +128,7 @@ class Context:
         """Brackets the launches of the named kernel groups (default: all) with HIP events."""
         mask = 0
         if on:
-            mask = (1 << len(T_GROUPS)) - 1 if groups is None else sum(1 << T_GROUPS.index(g) for g in groups)
+            mask = (1 << len(T_TOP)) - 1 if groups is None else sum(1 << T_GROUPS.index(g) for g in groups)
         self.lib.vo_set_timing(self.h, mask)
 
     def kernel_time_ms(self, group):
@@ -152,11 +155,19 @@ class Context:
         return kps[: n.value].copy(), (desc[: n.value].copy() if want_desc else None)
 
     def debug_level(self, image, level, blurred=False):
-        out = np.zeros(4096 * 4096 // 4, np.uint8)
         w, h = C.c_int(), C.c_int()
-        self._check(self.lib.vo_debug_level(self.h, image, level, int(blurred), _p(out), C.byref(w), C.byref(h)),
-                    "vo_debug_level")
+        # a first call with a zero capacity only reports the level's size
+        self.lib.vo_debug_level(self.h, image, level, int(blurred), None, 0, C.byref(w), C.byref(h))
+        out = np.zeros(max(w.value * h.value, 1), np.uint8)
+        self._check(self.lib.vo_debug_level(self.h, image, level, int(blurred), _p(out), out.size, C.byref(w),
+                                            C.byref(h)), "vo_debug_level")
         return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def fast_stats(self, enable):
+        """enable=True: start counting; False: stop and return dict(pixels, pretest_pass, corners, candidates)."""
+        out = np.zeros(4, np.uint64)
+        self._check(self.lib.vo_debug_fast_stats(self.h, int(bool(enable)), _p(out)), "vo_debug_fast_stats")
+        return dict(zip(("pixels", "pretest_pass", "corners", "candidates"), (int(v) for v in out)))
 
     def debug_candidates(self, image, level, cap=1 << 20):
         out = np.zeros((cap, 3), np.int32)

@@ -92,6 +92,8 @@ struct vo_ctx {
     // to truncate a list ORs into and that only take_truncation() clears; `img_status` holds one
     // word per image of the most recent detection call.
     vo::DevBuf flags, img_status;
+    vo::DevBuf fast_stats;                // four 64-bit scene counters (vo_debug_fast_stats)
+    bool fast_stats_on = false;
     uint32_t* img_status_cur = nullptr;   // the half of img_status the most recent detection call uses
     int status_phase = 0;
     const uint8_t* last_imgs = nullptr;
@@ -99,7 +101,7 @@ struct vo_ctx {
     vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist;
     // matching / RANSAC workspace
     vo::DevBuf m_top2, m_qidx, m_tidx, m_dist, m_p1, m_p2, m_cnt;
-    vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_counts, r_best, r_mask, r_pts, r_res;
+    vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_counts, r_best, r_mask, r_pts, r_res;
     // pipeline workspace
     vo::DevBuf p_kps, p_desc, p_cnt;
 };

@@ -5,6 +5,7 @@
 // stages keep OpenCV's operation order (built with -ffp-contract=off).
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 
 #include "vo_internal.h"
 
@@ -18,7 +19,8 @@ __device__ __attribute__((aligned(16))) int8_t d_pattern[256 * 4];
 // that half-wave lane hl (row hl >> 3 of a four-row group, dword hl & 7 of the 32-byte row
 // window starting at x - 15) loads in step t (patch row 4t - 15 + (hl >> 3)).
 __device__ uint32_t d_angle_mask[8 * 32];
-static bool g_pattern_loaded[64] = {false};
+static bool g_pattern_loaded[64] = {false};   // per GPU; guarded by g_pattern_mutex (contexts live on several host threads)
+static std::mutex g_pattern_mutex;
 
 struct SmallTabs {
     int umax[16];
@@ -245,7 +247,8 @@ __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, 
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
                                                    uint32_t tile_first, uint32_t ntiles, uint32_t tile_magic,
-                                                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+                                                   uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+                                                   unsigned long long* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t px[FP_H * FP_W];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
     __shared__ uint16_t q1[FQ_N], q2[FQ_N];
@@ -434,6 +437,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
     uint32_t n = nlist;
+    if (stats && tid == 0) {   // scene statistics (vo_debug_fast_stats), off in normal runs
+        const int lim_x = min(FT_W + 1, max_sx), lim_y = min(FS_H - 1, max_sy);
+        atomicAdd(&stats[0], (unsigned long long)((lim_x + 1) * (lim_y + 1)));
+        atomicAdd(&stats[1], (unsigned long long)n1);
+        atomicAdd(&stats[2], (unsigned long long)c2);
+        atomicAdd(&stats[3], (unsigned long long)n);
+    }
     if (n == 0) return;
     if (tid == 0) gbase = atomicAdd(&cand_cnt[img * kLevels + l], n);
     __syncthreads();
@@ -1403,6 +1413,9 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
         c->geom_valid = true;
     }
     g.n_images = n_images;
+    if (c->device < 0 || c->device >= 64) return fail(c, VO_ERR_INVALID, "device index beyond 63");
+    {
+    std::lock_guard<std::mutex> pattern_lock(g_pattern_mutex);
     if (!g_pattern_loaded[c->device]) {
         VO_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(d_pattern), h_pattern, sizeof(h_pattern)));
         static const SmallTabs tabs = make_tabs();
@@ -1417,6 +1430,7 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
             }
         VO_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(d_angle_mask), am.data(), am.size() * 4));
         g_pattern_loaded[c->device] = true;
+    }
     }
     size_t N = (size_t)n_images;
     int rc;
@@ -1463,7 +1477,8 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     auto launch_fast = [&](hipStream_t fs, uint32_t first, uint32_t count) {
         const uint32_t magic = (uint32_t)std::min<unsigned long long>(0x100000000ull / count, 0xFFFFFFFFull);
         hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(count * (uint32_t)N)), dim3(256), 0, fs, g, d_imgs, pyr,
-                           (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p, (uint32_t*)c->cand_cnt.p);
+                           (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p, (uint32_t*)c->cand_cnt.p,
+                           c->fast_stats_on ? (unsigned long long*)c->fast_stats.p : nullptr);
     };
     // The resize chain is seven dependent, bandwidth- and latency-bound launches that leave the
     // vector ALUs mostly idle, FAST is bound by them: level 0's FAST runs beside the chain on the
@@ -1613,13 +1628,16 @@ extern "C" int vo_orb_detect(vo_ctx* c, const uint8_t* img, int rows, int cols, 
     return VO_OK;
 }
 
-extern "C" int vo_debug_level(vo_ctx* c, int image, int level, int blurred, uint8_t* out, int* w, int* h) {
-    if (!c || !c->geom_valid || level < 0 || level >= kLevels || image < 0 || image >= c->g.n_images || !out)
+extern "C" int vo_debug_level(vo_ctx* c, int image, int level, int blurred, uint8_t* out, size_t out_bytes, int* w,
+                              int* h) {
+    if (!c || !c->geom_valid || level < 0 || level >= kLevels || image < 0 || image >= c->g.n_images)
         return c ? fail(c, VO_ERR_INVALID, "vo_debug_level: bad argument") : VO_ERR_INVALID;
     const Geom& g = c->g;
     const LevelGeom& L = g.L[level];
     if (w) *w = L.w;
     if (h) *h = L.h;
+    if (!out || out_bytes < (size_t)L.w * L.h)
+        return fail(c, VO_ERR_CAPACITY, "vo_debug_level: the level needs " + std::to_string((size_t)L.w * L.h) + " bytes");
     const uint8_t* src;
     size_t pitch;
     if (blurred) {
@@ -1634,6 +1652,24 @@ extern "C" int vo_debug_level(vo_ctx* c, int image, int level, int blurred, uint
     }
     VO_HIP(c, hipStreamSynchronize(c->stream));
     VO_HIP(c, hipMemcpy2D(out, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+extern "C" int vo_debug_fast_stats(vo_ctx* c, int enable, uint64_t out[4]) {
+    if (!c) return VO_ERR_INVALID;
+    VO_HIP(c, hipSetDevice(c->device));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->aux));
+    if (enable) {
+        if (int rc = ensure(c, c->fast_stats, 32)) return rc;
+        VO_HIP(c, hipMemset(c->fast_stats.p, 0, 32));
+        c->fast_stats_on = true;
+        return VO_OK;
+    }
+    if (!out) return fail(c, VO_ERR_INVALID, "vo_debug_fast_stats: out is NULL");
+    for (int k = 0; k < 4; ++k) out[k] = 0;
+    if (c->fast_stats_on) VO_HIP(c, hipMemcpy(out, c->fast_stats.p, 32, hipMemcpyDeviceToHost));
+    c->fast_stats_on = false;
     return VO_OK;
 }
 

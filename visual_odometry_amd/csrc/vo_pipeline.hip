@@ -17,7 +17,6 @@ __global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32
     res[p].n_kp2 = kp_cnt[pair_step * p + 1];
     res[p].n_matches = nmatch[p];
     res[p].status = (int32_t)(img_status[pair_step * p] | img_status[pair_step * p + 1]);
-    res[p].reserved = 0;
 }
 
 }  // namespace vo

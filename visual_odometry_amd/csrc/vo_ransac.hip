@@ -12,6 +12,7 @@
 // the serial loop would have picked.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 #include "vo_internal.h"
@@ -29,6 +30,7 @@ struct RState {
     int max_good;
     int done;
     int exact5;
+    int models_scored;   // candidates of the hypotheses the serial loop has walked
     double bestE[9];
 };
 
@@ -93,8 +95,10 @@ __device__ int update_num_iters(double p, double ep, int max_iters) {
 }
 
 __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__ n_arr, int n_max, int batch,
-                            RParams P, int32_t* __restrict__ samples, int samples_stride, int first_round) {
+                            RParams P, int32_t* __restrict__ samples, int samples_stride, int first_round,
+                            int32_t* __restrict__ retry_list) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) retry_list[0] = 0;
     if (b >= batch) return;
     RState s;
     s.rng = ~0ull;
@@ -104,6 +108,7 @@ __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__
     s.max_good = 0;
     s.done = s.n < 5;
     s.exact5 = s.n == 5;
+    s.models_scored = 0;
     for (int k = 0; k < 9; ++k) s.bestE[k] = 0;
     int32_t* out = samples + (size_t)b * samples_stride;
     if (s.exact5) {
@@ -195,13 +200,21 @@ __host__ __device__ int real_roots(const double* c, double* roots) {
         R += 1.0;
         int nc = 0;
         double a = -R, fa = poly_eval(d, deg, a);
+        bool pending = false;   // the extremum at `a` touches zero and the piece left of it held no root
         for (int k = 0; k <= np; ++k) {
             double b = k < np ? fmin(fmax(prev[k], -R), R) : R;
             double fb = poly_eval(d, deg, b);
+            const bool changed = b > a && fa != 0.0 && (fa < 0) != (fb < 0) && fb != 0.0;
+            if (pending && b > a) {
+                // no root on either side of the extremum: it is the double root itself
+                bool dup = nc > 0 && fabs(a - cur[nc - 1]) <= 1e-7 * fmax(1.0, fabs(a));
+                if (!changed && !dup && nc < 10) cur[nc++] = a;
+                pending = false;
+            }
             if (b > a) {
                 if (fa == 0.0) {
                     if (nc == 0 || cur[nc - 1] != a) cur[nc++] = a;
-                } else if ((fa < 0) != (fb < 0) && fb != 0.0) {
+                } else if (changed) {
                     // bracketed root: safeguarded Newton (Numerical-Recipes style rtsafe)
                     double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
                     double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold;
@@ -226,13 +239,14 @@ __host__ __device__ int real_roots(const double* c, double* roots) {
                     if (nc < 10 && !dup) cur[nc++] = x;
                 }
             }
-            if (j == 0 && k < np && fb != 0.0) {
-                // A local extremum that touches zero to rounding level is a double root
-                // (exactly degenerate data, e.g. pure sideways translation): keep it.
+            if (j == 0 && k < np && fb != 0.0 && b > a) {
+                // A local extremum that touches zero to rounding level with no sign change on
+                // either side is a double root (exactly degenerate data, e.g. pure sideways
+                // translation): kept once the next piece is known to hold no root either.  (Next
+                // to a sign change the bracketed roots already are the two solutions.)
                 double mag = fabs(d[deg]), ab = fabs(b);
                 for (int i = deg - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-                bool dup = nc > 0 && fabs(b - cur[nc - 1]) <= 1e-7 * fmax(1.0, ab);
-                if (fabs(fb) <= 1e-6 * mag && !dup && nc < 10) cur[nc++] = b;
+                pending = !changed && fabs(fb) <= 1e-6 * mag;
             }
             if (b > a) {
                 a = b;
@@ -281,13 +295,20 @@ __host__ __device__ __forceinline__ int roots_level(const double* c, const doubl
     int nc = 0;
     double last = 0;   // last root written (valid when nc > 0)
     double a = -R, fa = horner<DEG>(d, a);
+    bool pending = false;   // the extremum at `a` touches zero and the piece left of it held no root
     for (int k = 0; k <= np; ++k) {
         double b = k < np ? fmin(fmax(sP[k * ST], -R), R) : R;
         double fb = horner<DEG>(d, b);
+        const bool changed = b > a && fa != 0.0 && (fa < 0) != (fb < 0) && fb != 0.0;
+        if (DEG == 10 && pending && b > a) {
+            bool dup = nc > 0 && fabs(a - last) <= 1e-7 * fmax(1.0, fabs(a));
+            if (!changed && !dup && nc < 10) { sC[nc * ST] = a; last = a; ++nc; }
+            pending = false;
+        }
         if (b > a) {
             if (fa == 0.0) {
                 if (nc == 0 || last != a) { sC[nc * ST] = a; last = a; ++nc; }
-            } else if ((fa < 0) != (fb < 0) && fb != 0.0) {
+            } else if (changed) {
                 double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
                 double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold;
                 double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
@@ -311,13 +332,12 @@ __host__ __device__ __forceinline__ int roots_level(const double* c, const doubl
                 if (nc < 10 && !dup) { sC[nc * ST] = x; last = x; ++nc; }
             }
         }
-        if (DEG == 10 && k < np && fb != 0.0) {
+        if (DEG == 10 && k < np && fb != 0.0 && b > a) {
             double ab = fabs(b);
             double mag = fabs(d[DEG]);
 #pragma unroll
             for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-            bool dup = nc > 0 && fabs(b - last) <= 1e-7 * fmax(1.0, ab);
-            if (fabs(fb) <= 1e-6 * mag && !dup && nc < 10) { sC[nc * ST] = b; last = b; ++nc; }
+            pending = !changed && fabs(fb) <= 1e-6 * mag;
         }
         if (b > a) {
             a = b;
@@ -405,10 +425,11 @@ __host__ __device__ __forceinline__ void ess_constraints_dir(const double* E, co
 // constraint residual of the unit-norm result written to Eout.
 __host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout) {
     double E[9];
-    for (int it = 0; it <= 4; ++it) {
+    constexpr int kSteps = 12;
+    for (int it = 0; it <= kSteps; ++it) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) E[k] = B[0][k] * x + B[1][k] * y + B[2][k] * z + B[3][k];
-        if (it == 4) break;
+        if (it == kSteps) break;
         double f[10], J0[10], J1[10], J2[10];
         ess_constraints(E, f);
         ess_constraints_dir(E, B[0], J0);
@@ -432,7 +453,7 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
         double d2 = (n00 * (n11 * g2 - g1 * n12) - n01 * (n01 * g2 - g1 * n02) + g0 * c02) * inv;
         x -= d0; y -= d1; z -= d2;
         // converged: one more pass only rebuilds E from the final (x,y,z)
-        if (fmax(fabs(d0), fmax(fabs(d1), fabs(d2))) <= 1e-14 * fmax(1.0, fmax(fabs(x), fmax(fabs(y), fabs(z))))) it = 3;
+        if (fmax(fabs(d0), fmax(fabs(d1), fabs(d2))) <= 1e-14 * fmax(1.0, fmax(fabs(x), fmax(fabs(y), fabs(z))))) it = kSteps - 1;
     }
     double nrm = 0;
 #pragma unroll
@@ -452,7 +473,7 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
 // essential matrices (row-major) to Es.  sA: this lane's column of the
 // 10x20 elimination matrix in LDS (element (r,c) at sA[(r*20+c)*ST]).
 __host__ __device__ bool five_point_front(const double* x1, const double* x2, double* sA, double (*EE)[9],
-                                          double (*bm)[13], double* cf) {
+                                          double (*bm)[13], double* cf, int chart = 0) {
     // ---- null space of the 5x9 epipolar constraint matrix (Householder QR of its transpose)
     double M[9][5];
 #pragma unroll
@@ -507,7 +528,12 @@ __host__ __device__ bool five_point_front(const double* x1, const double* x2, do
     // four vectors with a fixed dense orthogonal matrix (I - 2uu^T,
     // u ~ (1, sqrt2, sqrt3, sqrt5)) removes such alignments.
     {
-        const double u[4] = {0.30151134457776363, 0.42640143271122088, 0.52223296786709361, 0.67419986246324204};
+        // (chart 1: a second, unrelated mixing - the same solutions through a differently
+        // conditioned elimination)
+        const double u0[4] = {0.30151134457776363, 0.42640143271122088, 0.52223296786709361, 0.67419986246324204};
+        const double u1[4] = {0.67419986246324204, -0.52223296786709361, 0.30151134457776363, -0.42640143271122088};
+        const double u2[4] = {0.5, -0.5, -0.5, 0.5};
+        const double* u = chart == 0 ? u0 : chart == 1 ? u1 : u2;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             double dot = u[0] * EE[0][i] + u[1] * EE[1][i] + u[2] * EE[2][i] + u[3] * EE[3][i];
@@ -694,9 +720,10 @@ __host__ __device__ __forceinline__ bool model_start(const double (*bm)[13], dou
 // x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm essential matrices
 // (row-major) to Es.  One lane does everything (host harness; the device path splits the
 // root search and the refinement over sixteen lanes, see solve_back).
-__host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA) {
+__host__ __device__ int five_point_dev(const double* x1, const double* x2, double* __restrict__ Es, double* sA,
+                                       int chart = 0) {
     double EE[4][9], bm[3][13], cf[11];
-    if (!five_point_front(x1, x2, sA, EE, bm, cf)) return 0;
+    if (!five_point_front(x1, x2, sA, EE, bm, cf, chart)) return 0;
     // the elimination matrix is no longer needed: its LDS column becomes the root lists
     int nr;
     {
@@ -717,7 +744,7 @@ __host__ __device__ int five_point_dev(const double* x1, const double* x2, doubl
         if (!model_start(bm, z1, &sx, &sy)) continue;
         double Ev[9];
         double res = polish_model_dev(EE, sx, sy, z1, Ev);
-        if (!(res <= 1e-9)) continue;   // did not settle on a solution
+        if (!(res <= 1e-12)) continue;   // did not settle on a solution
         bool dup = false;               // two starts that settled on the same solution
         for (int m = 0; m < count && !dup; ++m) {
             double dp = 0, dm = 0;
@@ -946,7 +973,9 @@ __device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
                 bool push;
                 if (t == 0) push = nc == 0 || last != v;
                 else if (t == 1) push = !(DEG == 10 && near);
-                else push = !near;
+                // a touching extremum is the double root itself only when neither neighbouring
+                // piece holds a bracketed root (next to one, the bracketed roots are the two solutions)
+                else push = !near && !(ty & 2) && !(sh.ptype[h][g + 1] & 2);
                 if (push && nc < 10) {
                     sC[nc] = v;
                     last = v;
@@ -962,11 +991,11 @@ __device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
 // Front end of one hypothesis per lane (ST lanes per workgroup, the elimination matrix in
 // LDS): writes the hypothesis record.
 __device__ __forceinline__ void solve_front(bool active, const double* x1, const double* x2, double* sA,
-                                            double* __restrict__ rec) {
+                                            double* __restrict__ rec, int chart = 0) {
     bool ok = false;
     if (active) {
         double EE[4][9], bm[3][13], cf[11];
-        ok = five_point_front(x1, x2, sA + threadIdx.x, EE, bm, cf);
+        ok = five_point_front(x1, x2, sA + threadIdx.x, EE, bm, cf, chart);
         if (ok) {
 #pragma unroll
             for (int i = 0; i < 11; ++i) rec[1 + i] = cf[i];
@@ -1061,7 +1090,7 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
 #pragma unroll
                 for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
             double res = polish_model_dev(EE, sx, sy, z1, Ev);
-            acc = res <= 1e-9;   // settled on a solution
+            acc = res <= 1e-12;   // settled on a solution
             if (acc) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
@@ -1148,16 +1177,96 @@ __global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restric
     solve_front(active, x1, x2, sA, recs + ((size_t)b * hr + h) * HYP_REC);
 }
 
+// Second pass over the hypotheses that came out of the first with an odd number of models.
+// Real solutions of the five-point problem come in pairs (the complex roots of the degree-10
+// polynomial are conjugate pairs), so an odd count says that one was lost: an ill-conditioned
+// elimination turned a close real pair into a complex one, or threw a root too far for the
+// refinement.  Those hypotheses (a few per thousand; the first back-end pass lists their slots
+// b * hr + h in retry_list[1 ..], count in retry_list[0]) are solved again in a second chart of
+// the null space, which conditions the same problem differently, and merge_models_kernel adds
+// what that finds beyond the first pass.  Entry i of the list gets record i and model block i.
+__global__ __launch_bounds__(ST) void retry_front_kernel(const double* __restrict__ m, int n_max,
+                                                         const int32_t* __restrict__ samples, int samples_stride, int hr,
+                                                         const int32_t* __restrict__ retry_list, double* __restrict__ recs) {
+    __shared__ double sA[200 * ST];
+    const int cnt = retry_list[0];
+    for (int base = blockIdx.x * ST; base < cnt; base += gridDim.x * ST) {
+        const int i = base + threadIdx.x;
+        if (i >= cnt) continue;   // (no barrier below: every lane works in its own LDS column)
+        const int slot = retry_list[1 + i], b = slot / hr, h = slot - b * hr;
+        double x1[10], x2[10];
+        const int32_t* idx = samples + (size_t)b * samples_stride + (size_t)h * 5;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const double* p = m + ((size_t)b * n_max + idx[k]) * 4;
+            x1[k * 2] = p[0]; x1[k * 2 + 1] = p[1];
+            x2[k * 2] = p[2]; x2[k * 2 + 1] = p[3];
+        }
+        solve_front(true, x1, x2, sA, recs + (size_t)i * HYP_REC, 1);
+    }
+}
+
+// Appends to a hypothesis' models those of the second pass that are not within 1e-7 (either
+// sign) of one it already has.  One lane per second-pass entry: entry i belongs to slot
+// retry_list[1 + i] (retry_list == nullptr: to slot i, `count` entries).
+__global__ __launch_bounds__(256) void merge_models_kernel(const int32_t* __restrict__ retry_list, int count,
+                                                           double* __restrict__ models, int32_t* __restrict__ nmodels,
+                                                           const double* __restrict__ models2,
+                                                           const int32_t* __restrict__ nmodels2) {
+    const int cnt = retry_list ? retry_list[0] : count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const size_t slot = retry_list ? (size_t)retry_list[1 + i] : (size_t)i;
+        const int n2 = nmodels2[i];
+        int n1 = nmodels[slot];
+        if (n2 == 0 || !(n1 & 1)) continue;
+        double* E1 = models + slot * kMaxModels * 9;
+        const double* E2 = models2 + (size_t)i * kMaxModels * 9;
+        for (int j = 0; j < n2 && n1 < kMaxModels; ++j) {
+            bool dup = false;
+            for (int k = 0; k < n1 && !dup; ++k) {
+                double dp = 0, dm = 0;
+                for (int q = 0; q < 9; ++q) {
+                    dp = fmax(dp, fabs(E1[k * 9 + q] - E2[j * 9 + q]));
+                    dm = fmax(dm, fabs(E1[k * 9 + q] + E2[j * 9 + q]));
+                }
+                dup = fmin(dp, dm) < 1e-7;
+            }
+            if (dup) continue;
+            for (int q = 0; q < 9; ++q) E1[n1 * 9 + q] = E2[j * 9 + q];
+            ++n1;
+        }
+        nmodels[slot] = n1;
+    }
+}
+
 __global__ __launch_bounds__(BACK_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
                                                                   const double* __restrict__ recs,
                                                                   double* __restrict__ models,
-                                                                  int32_t* __restrict__ nmodels) {
+                                                                  int32_t* __restrict__ nmodels,
+                                                                  int32_t* __restrict__ retry_list) {
     __shared__ BackShared sh;
     const int b = blockIdx.y;
     if (st[b].done) return;
     const int h0 = blockIdx.x * HB;
     const size_t slot = (size_t)b * hr + h0;
     solve_back_block(sh, min(HB, hr - h0), recs + slot * HYP_REC, models + slot * kMaxModels * 9, nmodels + slot);
+    // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
+    // the count it wrote itself)
+    if (retry_list && threadIdx.x < min(HB, hr - h0) && (nmodels[slot + threadIdx.x] & 1))
+        retry_list[1 + atomicAdd(&retry_list[0], 1)] = (int32_t)(slot + threadIdx.x);
+}
+
+__global__ __launch_bounds__(BACK_THREADS) void retry_back_kernel(const int32_t* __restrict__ retry_list,
+                                                                  const double* __restrict__ recs,
+                                                                  double* __restrict__ models2,
+                                                                  int32_t* __restrict__ nmodels2) {
+    __shared__ BackShared sh;
+    const int cnt = retry_list[0];
+    for (int base = blockIdx.x * HB; base < cnt; base += gridDim.x * HB) {   // workgroup-uniform
+        solve_back_block(sh, min(HB, cnt - base), recs + (size_t)base * HYP_REC, models2 + (size_t)base * kMaxModels * 9,
+                         nmodels2 + base);
+        __syncthreads();
+    }
 }
 
 // The inlier test (float)(err) <= t2 without the division in the common case: the
@@ -1225,10 +1334,11 @@ __global__ __launch_bounds__(64) void update_kernel(RState* __restrict__ stv, in
                                                     const double* __restrict__ models, const int32_t* __restrict__ nmodels,
                                                     const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
                                                     int samples_stride, int next_round, int32_t* __restrict__ samples_log,
-                                                    int log_cap) {
+                                                    int log_cap, int32_t* __restrict__ retry_list) {
     __shared__ int32_t s_nm[UPD_MAX_HR];
     __shared__ int32_t s_cnt[UPD_MAX_HR * kMaxModels];
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (b == 0 && lane == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
     if (stv[b].done) return;   // workgroup-uniform
     const int live = min(hr, max(stv[b].niters - h0, 0));   // hypotheses the serial loop can reach
     for (int h = lane; h < live; h += 64) s_nm[h] = nmodels[(size_t)b * hr + h];
@@ -1246,6 +1356,7 @@ __global__ __launch_bounds__(64) void update_kernel(RState* __restrict__ stv, in
         if (h0 + h >= s.niters) break;
         int nm = s_nm[h];
         if (s.exact5 && nm != 1) nm = 0;
+        s.models_scored += nm;
         for (int k = 0; k < nm; ++k) {
             int good = s_cnt[h * kMaxModels + k];
             if (good > max(s.max_good, 4)) {
@@ -1497,6 +1608,7 @@ __global__ __launch_bounds__(4 * FIN_T) void finish_kernel(const RState* __restr
             r->inliers = 0;
             r->valid = 0;
             r->ransac_iters = s.iters_run;
+            r->models_scored = s.models_scored;
             for (int k = 0; k < 9; ++k) r->R[k] = 0;
             for (int k = 0; k < 3; ++k) r->t[k] = 0;
         }
@@ -1588,7 +1700,8 @@ __global__ __launch_bounds__(4 * FIN_T) void finish_kernel(const RState* __restr
 // Five-point solver alone on caller-supplied minimal sets (normalised coordinates).
 __global__ __launch_bounds__(ST) void five_point_debug_front_kernel(const double* __restrict__ x1,
                                                                     const double* __restrict__ x2, int count,
-                                                                    double* __restrict__ recs) {
+                                                                    double* __restrict__ recs,
+                                                                    const int32_t* __restrict__ retry) {
     __shared__ double sA[200 * ST];
     const int h = blockIdx.x * ST + threadIdx.x;
     if (h >= count) return;
@@ -1597,7 +1710,8 @@ __global__ __launch_bounds__(ST) void five_point_debug_front_kernel(const double
         a[i] = x1[h * 10 + i];
         b[i] = x2[h * 10 + i];
     }
-    solve_front(true, a, b, sA, recs + (size_t)h * HYP_REC);
+    const bool active = !retry || (retry[h] & 1);
+    solve_front(active, a, b, sA, recs + (size_t)h * HYP_REC, retry ? 1 : 0);
 }
 
 __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int count, const double* __restrict__ recs,
@@ -1646,6 +1760,9 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if ((rc = ensure(c, c->r_samples, (size_t)batch * HR * 5 * 4))) return rc;
     if ((rc = ensure(c, c->r_models, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_nmodels, (size_t)batch * HR * 4))) return rc;
+    if ((rc = ensure(c, c->r_models2, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->r_nmodels2, (size_t)batch * HR * 4))) return rc;
+    if ((rc = ensure(c, c->r_retry, ((size_t)batch * HR + 1) * 4))) return rc;
     if ((rc = ensure(c, c->r_best, (size_t)batch * HR * HYP_REC * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
     RState* st = (RState*)c->r_state.p;
@@ -1653,6 +1770,9 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int32_t* samples = (int32_t*)c->r_samples.p;
     double* models = (double*)c->r_models.p;
     int32_t* nmodels = (int32_t*)c->r_nmodels.p;
+    double* models2 = (double*)c->r_models2.p;
+    int32_t* nmodels2 = (int32_t*)c->r_nmodels2.p;
+    int32_t* retry_list = (int32_t*)c->r_retry.p;
     double* recs = (double*)c->r_best.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
 
@@ -1663,21 +1783,36 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
     int r0 = std::min(round_size(0, fixed_iters), total);
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
-                       r0);
+                       r0, retry_list);
     int h0 = 0;
     for (int round = 0; h0 < total; ++round) {
         int hr = std::min(round_size(round, fixed_iters), total - h0);
         if (hr <= 0) break;
         int next = std::min(round_size(round + 1, fixed_iters), total - (h0 + hr));
         if (next < 0) next = 0;
+        t_begin_on(c, VO_T_RANSAC_SOLVE, s);
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
         hipLaunchKernelGGL(solve_back_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
-                           models, nmodels);
+                           models, nmodels, retry_list);
+        // second chart for the few hypotheses with an odd number of models: small fixed grids that
+        // stride over the list (its count is zeroed again by update_kernel)
+        static const bool no_retry = getenv("VO_NO_RETRY") != nullptr;   // measurement aid
+        if (!no_retry) {
+        hipLaunchKernelGGL(retry_front_kernel, dim3(256), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
+                           (const int32_t*)retry_list, recs);
+        hipLaunchKernelGGL(retry_back_kernel, dim3(64), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
+                           (const double*)recs, models2, nmodels2);
+        hipLaunchKernelGGL(merge_models_kernel, dim3(16), dim3(256), 0, s, (const int32_t*)retry_list, 0, models, nmodels,
+                           (const double*)models2, (const int32_t*)nmodels2);
+        }
+        t_end_on(c, VO_T_RANSAC_SOLVE, s);
+        t_begin_on(c, VO_T_RANSAC_SCORE, s);
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
+        t_end_on(c, VO_T_RANSAC_SCORE, s);
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
-                           counts, samples, HR * 5, next, d_samples, samples_cap);
+                           counts, samples, HR * 5, next, d_samples, samples_cap, retry_list);
         h0 += hr;
     }
     hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(4 * FIN_T), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
@@ -1792,10 +1927,20 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     VO_HIP(c, hipMemcpyAsync(d_in + (size_t)count * 10, x2, in_b, hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemsetAsync(c->r_models.p, 0, out_b, c->stream));
     if ((rc = ensure(c, c->r_best, (size_t)count * HYP_REC * 8))) return rc;
+    if ((rc = ensure(c, c->r_models2, out_b))) return rc;
+    if ((rc = ensure(c, c->r_nmodels2, (size_t)count * 4))) return rc;
     hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
-                       d_in + (size_t)count * 10, count, (double*)c->r_best.p);
+                       d_in + (size_t)count * 10, count, (double*)c->r_best.p, (const int32_t*)nullptr);
     hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream, count,
                        (const double*)c->r_best.p, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
+    // the second-chart pass for odd model counts, as in the RANSAC rounds
+    hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
+                       d_in + (size_t)count * 10, count, (double*)c->r_best.p, (const int32_t*)c->r_nmodels.p);
+    hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream, count,
+                       (const double*)c->r_best.p, (double*)c->r_models2.p, (int32_t*)c->r_nmodels2.p);
+    hipLaunchKernelGGL(merge_models_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const int32_t*)nullptr,
+                       count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p, (const double*)c->r_models2.p,
+                       (const int32_t*)c->r_nmodels2.p);
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(n_models, c->r_nmodels.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));

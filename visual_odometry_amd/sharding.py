@@ -33,3 +33,16 @@ def gather_rows(local, n_total, dst=0):
     if rank != dst:
         return None
     return torch.cat([o[: e - b] for o, (b, e) in zip(out, sizes)], 0)
+
+
+def sharded_knn2(knn2, q_all, t, dst=0):
+    """Brute-force 2-nearest-neighbour table of q_all against t with the QUERY ROWS sharded over
+    the ranks: this rank runs knn2(q_rows, t) -> (idx2, dist2), two (rows, 2) int32 tensors, on
+    its block_range of q_all, and the (rows, 4) blocks [idx2 | dist2] are gathered on `dst` with
+    one collective.  Every rank holds all of t, so each block is final and nothing is reduced.
+    Returns the (len(q_all), 4) table on dst, None elsewhere."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    b, e = block_range(len(q_all), rank, world)
+    idx2, dist2 = knn2(q_all[b:e], t)
+    return gather_rows(torch.cat([idx2, dist2], 1), len(q_all), dst=dst)

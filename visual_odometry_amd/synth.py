@@ -35,17 +35,21 @@ def _box3(img):
     return out / 9.0
 
 
-def _texture(rng, h, w):
+def _texture(rng, h, w, sparse=False):
     """Blocky texture with corners at several scales: 16-px base cells plus 32-px and
-    8-px ternary patterns, slightly blurred.  About a quarter of the pixels pass FAST's
-    cardinal pre-test and ~2 % are corners at full resolution - busier than indoor or
-    road scenes, so every pyramid level still fills its keypoint quota."""
-    img = rng.integers(40, 216, size=(h // 16 + 2, w // 16 + 2)).astype(np.float32)
-    img = np.kron(img, np.ones((16, 16), np.float32))[:h, :w]
-    for cell, amp in ((32, 40.0), (8, 40.0)):
+    8-px ternary patterns, slightly blurred.  Dense: about a quarter of the pixels pass
+    FAST's cardinal pre-test and every pyramid level over-fills its keypoint quota many
+    times - far busier than indoor or road scenes.  sparse=True: 40-px cells with one
+    80-px pattern, blurred twice - a few corners per thousand pixels, like a real frame."""
+    base, cells, blurs = (40, ((80, 30.0),), 2) if sparse else (16, ((32, 40.0), (8, 40.0)), 1)
+    img = rng.integers(40, 216, size=(h // base + 2, w // base + 2)).astype(np.float32)
+    img = np.kron(img, np.ones((base, base), np.float32))[:h, :w]
+    for cell, amp in cells:
         g = rng.integers(-1, 2, size=(h // cell + 2, w // cell + 2)).astype(np.float32)
         img += amp * np.kron(g, np.ones((cell, cell), np.float32))[:h, :w]
-    return _box3(img)
+    for _ in range(blurs):
+        img = _box3(img)
+    return img
 
 
 def _rotation(rx, ry, rz):
@@ -73,26 +77,35 @@ def _warp_rotation(img, K, R):
             ay * ((1 - ax) * img[y0 + 1, x0] + ax * img[y0 + 1, x0 + 1]))
 
 
-def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0, K=None, rot_deg=(0.4, -0.7, 1.1)):
+def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0, K=None, rot_deg=(0.4, -0.7, 1.1), sparse=False,
+               moving_fraction=0.0):
     """Returns (frame_a, frame_b) as uint8 arrays of shape (height, width).
 
     rot_deg: camera rotation (about x, y, z, degrees) between the frames, applied on
     top of the sideways translation; (0, 0, 0) leaves the exactly degenerate
-    pure-translation geometry with horizontal integer disparities."""
+    pure-translation geometry with horizontal integer disparities.
+    sparse: low-texture scene (see _texture).  moving_fraction: share of the layers that
+    move on their own (a vertical shift no camera motion explains): their matches are the
+    outliers of the essential-matrix fit."""
     rng = np.random.default_rng(seed)
     pad = 48
     W = width + 2 * pad
-    a = _texture(rng, height, W)
+    a = _texture(rng, height, W, sparse)
     b = np.roll(a, -12, axis=1)  # background: disparity 12 px
-    for _ in range(n_layers):
+    for j in range(n_layers):
         h = int(rng.integers(height // 6, height // 2))
         w = int(rng.integers(width // 8, width // 3))
         y = int(rng.integers(0, height - h))
         x = int(rng.integers(pad, W - pad - w))
         d = int(rng.integers(14, 41))
-        tex = _texture(rng, h, w)
+        tex = _texture(rng, h, w, sparse)
         a[y:y + h, x:x + w] = tex
-        b[y:y + h, x - d:x - d + w] = tex
+        if moving_fraction > 0 and rng.random() < moving_fraction:
+            dy = int(rng.integers(6, 25)) * (1 if rng.random() < 0.5 else -1)
+            y2 = min(max(y + dy, 0), height - h)
+            b[y2:y2 + h, x - d:x - d + w] = tex
+        else:
+            b[y:y + h, x - d:x - d + w] = tex
     a = a[:, pad:pad + width]
     b = b[:, pad:pad + width]
     if any(rot_deg):
@@ -102,6 +115,48 @@ def frame_pair(seed, height=480, width=640, n_layers=12, noise=3.0, K=None, rot_
     b = b + rng.normal(0.0, noise, b.shape)
     return (np.clip(np.rint(a), 0, 255).astype(np.uint8),
             np.clip(np.rint(b), 0, 255).astype(np.uint8))
+
+
+def sequence(seed, n_frames, height=480, width=640, n_layers=12, noise=3.0, K=None, rot_amp_deg=(0.4, 0.7, 1.1)):
+    """n_frames consecutive views of one layered scene from a camera that moves one baseline
+    along +x per frame and wobbles a little: a stand-in for a TUM / KITTI directory.
+
+    Every layer is a periodic texture behind a rectangular mask on a canvas wider than the
+    view; frame k shows layer j rolled left by k * d_j pixels (d_j = its integer disparity per
+    frame, 12-40 px, the background 12), nearer layers on top, then rotated by R_k (exact
+    homography warp) and given independent pixel noise.  Consecutive frames therefore obey a
+    real two-view geometry, like the two frames of frame_pair()."""
+    rng = np.random.default_rng(seed)
+    Wc = 2 * width                                  # canvas: masks re-enter far outside the view
+    layers = [(12, _texture(rng, height, Wc), None)]
+    for _ in range(n_layers):
+        h = int(rng.integers(height // 6, height // 2))
+        w = int(rng.integers(width // 8, width // 3))
+        y = int(rng.integers(0, height - h))
+        x = int(rng.integers(0, Wc - w))
+        d = int(rng.integers(14, 41))
+        mask = np.zeros((height, Wc), bool)
+        mask[y:y + h, x:x + w] = True
+        layers.append((d, _texture(rng, height, Wc), mask))
+    layers.sort(key=lambda t: t[0])                 # far to near
+    Kc = K if K is not None else default_K(width, height)
+    frames = []
+    for k in range(n_frames):
+        view = None
+        for d, tex, mask in layers:
+            t = np.roll(tex, -k * d, axis=1)[:, :width]
+            if mask is None:
+                view = t.copy()
+            else:
+                m = np.roll(mask, -k * d, axis=1)[:, :width]
+                view[m] = t[m]
+        ang = np.radians([rot_amp_deg[0] * np.sin(0.30 * k), rot_amp_deg[1] * np.sin(0.21 * k + 1.0),
+                          rot_amp_deg[2] * np.sin(0.17 * k + 2.0)])
+        if np.any(ang != 0):
+            view = _warp_rotation(view, Kc, _rotation(*ang))
+        view = view + rng.normal(0.0, noise, view.shape)
+        frames.append(np.clip(np.rint(view), 0, 255).astype(np.uint8))
+    return frames
 
 
 def checkerboard(height=480, width=640, cell=32, shift=0, noise_sigma=25.0, seed=0):
