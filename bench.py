@@ -125,6 +125,7 @@ def cpu_baseline(frames, K, cfg, budget_s=12.0):
     loop does per pair) and ms per match_images call with estimate_motion outside the timed
     region (ref:benchmarks/benchmark_matchers.cpp:111-135)."""
     from oracle import oracle as O
+    O.set_five_point_charts(1)   # OpenCV's single chart (the parity checks use the union over four)
     nfeat, fixed = cfg["nfeat"], cfg["fixed"]
     if cfg["sequence"]:
         pair_frames = [(frames[i], frames[i + 1]) for i in range(len(frames) - 1)]
@@ -165,6 +166,7 @@ def cpu_baseline(frames, K, cfg, budget_s=12.0):
     dt = time.perf_counter() - t0
     out["multi_thread"] = {"value": threads * per_thread / dt, "unit": "frame-pairs/s", "cores": threads,
                            "sample": f"{threads * per_thread} frame pairs on {threads} threads, {dt:.1f} s"}
+    O.set_five_point_charts(4)
     return out
 
 

@@ -208,6 +208,18 @@ int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int r
                           double threshold, double confidence, int fixed_iters,
                           vo_pair_result* d_results);
 
+/* match_images_orb (ref:src/image_matcher.cpp:71-81; orb_matcher::match_images,
+ * ref:include/visual_odometry/image_matcher.hpp:52-55) for ONE pair of host
+ * images, what the reference's main loop (ref:src/main.cpp:162) and benchmark
+ * (ref:benchmarks/benchmark_matchers.cpp:112) call per pair: detect both, match,
+ * ratio test.  One upload of the two images, one download of both keypoint sets
+ * (at most `cap` each) and the surviving matches (at most `cap`: query index,
+ * train index, distance, in query order); descriptors stay in HBM.  Returns
+ * when the outputs are written.  rows * cols == 0 gives all counts 0. */
+int vo_match_images(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int rows, int cols, int step,
+                    int max_features, float ratio, vo_keypoint* kps1, int* n_kps1, vo_keypoint* kps2, int* n_kps2,
+                    int cap, int32_t* query_idx, int32_t* train_idx, float* distance, int* n_matches);
+
 /* The same for a video sequence: n_frames consecutive frames in d_imgs give the
  * n_frames - 1 pairs (i, i+1), as the reference's main loop walks a directory
  * (ref:src/main.cpp:152-184, which detects every frame twice, once per pair it

@@ -78,7 +78,19 @@ static void matcher_tests() {
     EXPECT(vo::match_features(r1.descriptors, none, r1.keypoints, {}, {}).matches.size() == 0);
     vo::orb_matcher om;                                              // matcher_like wrapper
     EXPECT(om.name() == "ORB");
-    EXPECT(om.match_images(a, b).matches.size() == m.matches.size());
+    // the fused pair call gives, element for element, what detect x2 + match give
+    auto fused = om.match_images(a, b);
+    EXPECT(fused.matches.size() == m.matches.size());
+    EXPECT(fused.points1.size() == m.points1.size() && fused.points2.size() == m.points2.size());
+    for (size_t i = 0; i < m.matches.size() && i < fused.matches.size(); ++i) {
+        EXPECT(fused.matches[i].queryIdx == m.matches[i].queryIdx && fused.matches[i].trainIdx == m.matches[i].trainIdx);
+        EXPECT(fused.matches[i].distance == m.matches[i].distance && fused.matches[i].imgIdx == 0);
+        EXPECT(fused.points1[i] == m.points1[i] && fused.points2[i] == m.points2[i]);
+    }
+    cv::Mat none_img;
+    EXPECT(om.match_images(none_img, b).matches.size() == 0);      // empty image -> empty result
+    cv::Mat small(240, 320, CV_8UC1, cv::Scalar(128));                // different shapes take the three-call route
+    EXPECT(om.match_images(a, small).matches.size() == 0);
     bool threw = false;
     try { (void)vo::create_image_matcher("nope"); } catch (std::runtime_error const& e) { threw = std::string(e.what()).find("Unknown matcher") != std::string::npos; }
     EXPECT(threw);

@@ -501,6 +501,22 @@ def test_c1_sequence_of_101_frames_1000_keypoints(ctx, oracle):
             assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4, p
 
 
+@pytest.mark.parametrize("shape,nfeat", [((480, 640), 2000), ((376, 1241), 1000), ((301, 423), 300)])
+def test_match_images_host_pair_call(ctx, oracle, shape, nfeat):
+    """vo_match_images (one upload, one download, descriptors stay in HBM) against the oracle's
+    detect x2 + match: keypoint records of both images byte for byte, matches in query order."""
+    a, b = synth.frame_pair(90 + nfeat, height=shape[0], width=shape[1])
+    k1, k2, qi, ti, d = ctx.match_images(a, b, nfeat, 0.75)
+    oa, da = oracle.orb_detect(a, nfeat)
+    ob, db = oracle.orb_detect(b, nfeat)
+    oq, ot, od = oracle.match(da, db, 0.75)
+    assert k1.tobytes() == oa.tobytes() and k2.tobytes() == ob.tobytes()
+    assert len(oq) > 20
+    assert np.array_equal(qi, oq) and np.array_equal(ti, ot) and np.array_equal(d, od)
+    k1, k2, qi, ti, d = ctx.match_images(a, np.full(shape, 128, np.uint8), nfeat, 0.75)   # nothing to match against
+    assert len(k1) == len(oa) and len(k2) == 0 and len(qi) == 0
+
+
 # ------------------------------------------------------------------ fused pipeline
 def test_pipeline_pairs_matches_oracle(ctx, oracle):
     import torch

@@ -1,0 +1,12 @@
+#!/bin/bash
+# SQ counters of the FAST kernel alone (tools/fast_bench.py): tools/pmc_fast.sh [--sparse]
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/pmc_fast
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+A="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_ANY"
+B="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+timeout -s KILL 120 rocprofv3 --pmc $A --output-format csv -d $OUT/a -- python3 $R/tools/fast_bench.py "$@" > $OUT/a.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc $B --output-format csv -d $OUT/b -- python3 $R/tools/fast_bench.py "$@" > $OUT/b.log 2>&1 || exit 1
+python3 $R/tools/pmc_summary.py $OUT/a $OUT/b | grep -E "kernel |fast_kernel"

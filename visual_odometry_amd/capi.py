@@ -25,7 +25,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
-    "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
+    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
@@ -75,6 +75,8 @@ def load():
     lib.vo_match_ratio_static.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, vp]
     lib.vo_estimate_motion.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
     lib.vo_find_essential.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
+    lib.vo_match_images.argtypes = [vp, vp, vp, i, i, i, i, f, vp, C.POINTER(i), vp, C.POINTER(i), i, vp, vp, vp,
+                                    C.POINTER(i)]
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
@@ -194,6 +196,27 @@ class Context:
         self._check(self.lib.vo_match_ratio(self.h, _p(q), len(q), _p(t), len(t), float(ratio), _p(qi), _p(ti),
                                             _p(d), C.byref(m)), "vo_match_ratio")
         return qi[: m.value].copy(), ti[: m.value].copy(), d[: m.value].copy()
+
+    def match_images(self, img1, img2, max_features=2000, ratio=0.75):
+        """match_images_orb for one pair of host images: (kps1, kps2, query_idx, train_idx, distance)."""
+        img1 = np.ascontiguousarray(img1, np.uint8)
+        img2 = np.ascontiguousarray(img2, np.uint8)
+        if img1.shape != img2.shape:
+            raise ValueError("the two images must have the same shape")
+        rows, cols = img1.shape
+        cap = max_features + 8 * 256
+        bufs = getattr(self, "_mi_bufs", None)
+        if bufs is None or bufs[0] != cap:
+            bufs = (cap, np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE), np.zeros(cap, np.int32),
+                    np.zeros(cap, np.int32), np.zeros(cap, np.float32))
+            self._mi_bufs = bufs
+        _, k1, k2, qi, ti, d = bufs
+        n1, n2, m = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.vo_match_images(self.h, _p(img1), _p(img2), rows, cols, img1.strides[0], int(max_features),
+                                             float(ratio), _p(k1), C.byref(n1), _p(k2), C.byref(n2), cap, _p(qi),
+                                             _p(ti), _p(d), C.byref(m)), "vo_match_images")
+        return (k1[: n1.value].copy(), k2[: n2.value].copy(), qi[: m.value].copy(), ti[: m.value].copy(),
+                d[: m.value].copy())
 
     def estimate_motion(self, p1, p2, K, threshold=1.0, confidence=0.999, fixed_iters=0):
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)

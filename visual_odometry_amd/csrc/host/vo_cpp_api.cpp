@@ -8,6 +8,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include <visual_odometry/feature_detector.hpp>
 #include <visual_odometry/feature_matcher.hpp>
@@ -23,6 +24,10 @@ namespace {
 struct thread_ctx {
     vo_ctx* c{nullptr};
     std::string err;
+    // reusable result buffers of match_images_orb
+    std::vector<vo_keypoint> k1, k2;
+    std::vector<int32_t> qi, ti;
+    std::vector<float> dist;
     ~thread_ctx() {
         if (c) vo_ctx_destroy(c);
     }
@@ -142,9 +147,46 @@ auto match_features(cv::Mat const& descriptors1, cv::Mat const& descriptors2, st
 
 auto match_images_orb(cv::Mat const& img1, cv::Mat const& img2, feature_detector_config const& detector_config,
                       feature_matcher_config const& matcher_config) -> match_result {
-    auto const det1 = detect_features(img1, detector_config);
-    auto const det2 = detect_features(img2, detector_config);
-    return match_features(det1.descriptors, det2.descriptors, det1.keypoints, det2.keypoints, matcher_config);
+    // One fused call (vo_match_images): the two images go up once, the descriptors never leave
+    // the GPU, keypoint sets and matches come back once.  Images of different shape or type take
+    // the three-call route the reference spells out.
+    if (img1.empty() || img2.empty() || img1.rows != img2.rows || img1.cols != img2.cols || img1.step != img2.step ||
+        img1.type() != CV_8UC1 || img2.type() != CV_8UC1 || detector_config.max_features <= 0) {
+        auto const det1 = detect_features(img1, detector_config);
+        auto const det2 = detect_features(img2, detector_config);
+        return match_features(det1.descriptors, det2.descriptors, det1.keypoints, det2.keypoints, matcher_config);
+    }
+    match_result r;
+    vo_ctx* c = ctx();
+    if (!c) return r;
+    int const cap = detector_config.max_features + 8 * 256;
+    auto& t = tls();
+    t.k1.resize((size_t)cap);
+    t.k2.resize((size_t)cap);
+    t.qi.resize((size_t)cap);
+    t.ti.resize((size_t)cap);
+    t.dist.resize((size_t)cap);
+    int n1 = 0, n2 = 0, m = 0;
+    if (!ok(vo_match_images(c, img1.data, img2.data, img1.rows, img1.cols, (int)img1.step, detector_config.max_features,
+                            matcher_config.ratio_threshold, t.k1.data(), &n1, t.k2.data(), &n2, cap, t.qi.data(),
+                            t.ti.data(), t.dist.data(), &m)))
+        return r;
+    r.matches.reserve((size_t)m);
+    r.points1.reserve((size_t)m);
+    r.points2.reserve((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        cv::DMatch dm;
+        dm.queryIdx = t.qi[(size_t)i];
+        dm.trainIdx = t.ti[(size_t)i];
+        dm.imgIdx = 0;
+        dm.distance = t.dist[(size_t)i];
+        r.matches.push_back(dm);
+        vo_keypoint const& a = t.k1[(size_t)dm.queryIdx];
+        vo_keypoint const& b = t.k2[(size_t)dm.trainIdx];
+        r.points1.emplace_back(a.x, a.y);
+        r.points2.emplace_back(b.x, b.y);
+    }
+    return r;
 }
 
 auto create_image_matcher(std::string_view name) -> image_matcher {

@@ -98,7 +98,9 @@ struct vo_ctx {
     int status_phase = 0;
     const uint8_t* last_imgs = nullptr;
     // staging for the host-buffer entry points
-    vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist;
+    vo::DevBuf st_img, st_kps, st_desc, st_cnt, st_q, st_t, st_idx, st_dist, st_down;
+    void* h_pin = nullptr;       // pinned host staging of vo_match_images (upload and download block)
+    size_t h_pin_bytes = 0;
     // matching / RANSAC workspace
     vo::DevBuf m_top2, m_qidx, m_tidx, m_dist, m_p1, m_p2, m_cnt;
     vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_counts, r_best, r_mask, r_pts, r_res;

@@ -2,6 +2,9 @@
 // every intermediate resident in HBM.  Stands in for match_images_orb
 // (ref:src/image_matcher.cpp:71-81) followed by estimate_motion as the
 // reference's main loop chains them (ref:src/main.cpp:162-170).
+#include <algorithm>
+#include <cstring>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -117,4 +120,74 @@ extern "C" int vo_pipeline_sequence(vo_ctx* c, const uint8_t* imgs, int n_frames
     // on a truncated keypoint list the records still go out (status names the pairs concerned)
     VO_HIP(c, hipMemcpy(results, c->r_res.p, res_bytes, hipMemcpyDeviceToHost));
     return rc;
+}
+
+// match_images_orb (ref:src/image_matcher.cpp:71-81) for one pair of host images in one round
+// trip: both images go up in one copy, detection runs on the two-image batch, the matcher and
+// the ratio test read the descriptors where the detector left them, and keypoints, matches and
+// counts come back in one copy - no descriptor ever crosses the bus.  Pinned staging on both
+// sides keeps the copies asynchronous; the call waits once.
+extern "C" int vo_match_images(vo_ctx* c, const uint8_t* img1, const uint8_t* img2, int rows, int cols, int step,
+                               int max_features, float ratio, vo_keypoint* kps1, int* n_kps1, vo_keypoint* kps2,
+                               int* n_kps2, int cap, int32_t* query_idx, int32_t* train_idx, float* distance,
+                               int* n_matches) {
+    if (!c) return VO_ERR_INVALID;
+    if (!n_kps1 || !n_kps2 || !n_matches) return fail(c, VO_ERR_INVALID, "vo_match_images: a count pointer is NULL");
+    *n_kps1 = *n_kps2 = *n_matches = 0;
+    if (!img1 || !img2 || rows <= 0 || cols <= 0) return VO_OK;   // an empty image has no features: no matches
+    if (step < cols || cap <= 0 || max_features <= 0 || !kps1 || !kps2 || !query_idx || !train_idx || !distance)
+        return fail(c, VO_ERR_INVALID, "vo_match_images: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    int rc;
+    const size_t img_bytes = (size_t)rows * step;
+    const size_t kp_bytes = (size_t)cap * sizeof(vo_keypoint);
+    // download block: [n1, n2, n_matches, pad | kps1 | kps2 | qidx | tidx | dist]
+    const size_t off_k1 = 16, off_k2 = off_k1 + kp_bytes, off_q = off_k2 + kp_bytes, off_t = off_q + (size_t)cap * 4,
+                 off_d = off_t + (size_t)cap * 4, down_bytes = off_d + (size_t)cap * 4;
+    const size_t pin_bytes = std::max(2 * img_bytes, down_bytes);
+    if (c->h_pin_bytes < pin_bytes) {
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr;
+        c->h_pin_bytes = 0;
+        VO_HIP(c, hipHostMalloc(&c->h_pin, pin_bytes, hipHostMallocDefault));
+        c->h_pin_bytes = pin_bytes;
+    }
+    if ((rc = ensure(c, c->st_img, 2 * img_bytes))) return rc;
+    if ((rc = ensure(c, c->st_down, down_bytes))) return rc;
+    if ((rc = ensure(c, c->st_desc, 2 * (size_t)cap * 32))) return rc;
+    if ((rc = ensure(c, c->st_idx, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(c, c->st_dist, (size_t)cap * 8))) return rc;
+    if ((rc = join_side(c))) return rc;   // a pipeline call's tail may still use the staging and match buffers
+    uint8_t* pin = (uint8_t*)c->h_pin;
+    std::memcpy(pin, img1, img_bytes);
+    std::memcpy(pin + img_bytes, img2, img_bytes);
+    VO_HIP(c, hipMemcpyAsync(c->st_img.p, pin, 2 * img_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orb_prepare(c, 2, rows, cols, step, img_bytes, max_features))) return rc;
+    uint8_t* down = (uint8_t*)c->st_down.p;
+    int32_t* d_cnt = (int32_t*)down;
+    vo_keypoint* d_kps = (vo_keypoint*)(down + off_k1);
+    uint8_t* d_desc = (uint8_t*)c->st_desc.p;
+    if ((rc = orb_run(c, (const uint8_t*)c->st_img.p, d_kps, d_desc, cap, d_cnt))) return rc;
+    if ((rc = knn2_launch(c, d_desc, d_cnt, 1, cap, 0, d_desc + (size_t)cap * 32, d_cnt + 1, cap, 0, 1, (int32_t*)c->st_idx.p,
+                          (int32_t*)c->st_dist.p, max_features)))
+        return rc;
+    if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, d_cnt, 1, cap, 1, ratio, nullptr,
+                           nullptr, 0, (int32_t*)(down + off_q), (int32_t*)(down + off_t), (float*)(down + off_d), nullptr,
+                           nullptr, d_cnt + 2, c->stream)))
+        return rc;
+    VO_HIP(c, hipMemcpyAsync(pin, down, down_bytes, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = take_truncation(c, "vo_match_images"))) return rc;
+    const int32_t* h_cnt = (const int32_t*)pin;
+    const int n1 = h_cnt[0], n2 = h_cnt[1], m = h_cnt[2];
+    std::memcpy(kps1, pin + off_k1, (size_t)n1 * sizeof(vo_keypoint));
+    std::memcpy(kps2, pin + off_k2, (size_t)n2 * sizeof(vo_keypoint));
+    std::memcpy(query_idx, pin + off_q, (size_t)m * 4);
+    std::memcpy(train_idx, pin + off_t, (size_t)m * 4);
+    std::memcpy(distance, pin + off_d, (size_t)m * 4);
+    *n_kps1 = n1;
+    *n_kps2 = n2;
+    *n_matches = m;
+    return VO_OK;
 }
