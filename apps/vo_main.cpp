@@ -26,6 +26,7 @@ struct options {
     std::string matcher{"orb"};
     int max_frames{0};
     int batch{64};   // frame pairs per GPU call
+    int gpus{1};     // GPUs the pairs of a batch are split over (devices 0 .. gpus - 1)
 };
 
 void usage(std::string_view program) {
@@ -37,6 +38,7 @@ void usage(std::string_view program) {
               << "  --matcher <name>   Feature matcher: orb (default)\n"
               << "  --max-frames <n>   Maximum frames to process (default: all)\n"
               << "  --batch <n>        Frame pairs per GPU call (default: 64)\n"
+              << "  --gpus <n>         GPUs to split every batch over, devices 0..n-1 (default: 1)\n"
               << "  --help             Show this help message\n";
 }
 
@@ -55,6 +57,7 @@ auto parse(int argc, char** argv) -> std::optional<options> {
         else if (a == "--matcher" && (v = value())) o.matcher = v;
         else if (a == "--max-frames" && (v = value())) o.max_frames = std::atoi(v);
         else if (a == "--batch" && (v = value())) o.batch = std::max(1, std::atoi(v));
+        else if (a == "--gpus" && (v = value())) o.gpus = std::max(1, std::atoi(v));
         else {
             std::cerr << "Unknown argument: " << a << "\n";
             usage(argv[0]);
@@ -117,43 +120,79 @@ int main(int argc, char** argv) {
     size_t const max_pairs = opt->max_frames > 0 ? std::min((size_t)opt->max_frames, total_pairs) : total_pairs;
     std::cout << "\nProcessing " << max_pairs << " frame pairs...\n";
 
+    std::vector<int> devices;
+    if (opt->gpus > 1)
+        for (int d = 0; d < opt->gpus; ++d) devices.push_back(d);
+
     int valid_motions = 0;
-    std::optional<cv::Mat> carried;   // last frame of the previous batch
+    // one pair's outcome, reported and accumulated in pair order
+    auto account = [&](size_t i, vo::sequence_step const& st) {
+        if (trajectory.add_motion(st.motion, loader->get_timestamp(i + 1))) ++valid_motions;
+        if ((i + 1) % 100 == 0 || i == max_pairs - 1)
+            std::cout << "  Frame " << std::setw(5) << (i + 1) << "/" << max_pairs << " | Matches: " << st.matches
+                      << " | Inliers: " << st.motion.inliers << (st.motion.valid ? "" : " [FAILED]") << "\n";
+    };
+    // a pair on its own, as the reference's loop treats every pair (ref:src/main.cpp:162-170): the
+    // route for pairs that cannot ride in a batch (frames of different size, a batch that failed)
+    auto single_pair = [&](cv::Mat const& a, cv::Mat const& b) {
+        vo::sequence_step st;
+        auto const m = vo::match_images_orb(a, b, vo::feature_detector_config{.max_features = max_features},
+                                            vo::feature_matcher_config{.ratio_threshold = ratio});
+        st.matches = (int)m.matches.size();
+        st.motion = vo::estimate_motion(m.points1, m.points2, *intrinsics);
+        return st;
+    };
+    std::optional<cv::Mat> carried;   // last frame of the previous batch (nullopt: it failed to load)
+    bool have_carried = false;
     for (size_t first = 0; first < max_pairs; first += (size_t)opt->batch) {
         size_t const n_pairs = std::min((size_t)opt->batch, max_pairs - first);
-        std::vector<cv::Mat> frames;
-        std::vector<size_t> index;   // frame index of each loaded image
-        bool failed = false;
-        for (size_t k = 0; k <= n_pairs && !failed; ++k) {
-            if (k == 0 && carried) {
-                frames.push_back(*carried);
-                index.push_back(first);
+        // frames first .. first + n_pairs; a frame that fails to load costs only the pairs it
+        // belongs to, as in the reference (ref:src/main.cpp:152-158)
+        std::vector<std::optional<cv::Mat>> frames(n_pairs + 1);
+        std::vector<std::string> load_error(n_pairs + 1);
+        for (size_t k = 0; k <= n_pairs; ++k) {
+            if (k == 0 && have_carried) {
+                frames[0] = carried;
                 continue;
             }
             auto img = loader->load_image(first + k);
-            if (!img.has_value()) {
-                std::cerr << "Warning: Failed to load pair " << (first + (k ? k - 1 : 0)) << ": " << img.error() << "\n";
-                failed = true;
-                break;
+            if (img.has_value() && !img.value().empty()) frames[k] = img.value();
+            else load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+        }
+        std::vector<std::optional<vo::sequence_step>> steps(n_pairs);
+        // maximal runs of loaded frames of one size and type go to the GPU in one call each
+        size_t k = 0;
+        while (k <= n_pairs) {
+            if (!frames[k]) { ++k; continue; }
+            size_t e = k + 1;
+            while (e <= n_pairs && frames[e] && frames[e]->rows == frames[k]->rows && frames[e]->cols == frames[k]->cols &&
+                   frames[e]->type() == frames[k]->type())
+                ++e;
+            if (e - k >= 2 && frames[k]->type() == CV_8UC1) {
+                std::vector<cv::Mat> run;
+                for (size_t j = k; j < e; ++j) run.push_back(*frames[j]);
+                auto const got = vo::process_sequence(run, *intrinsics, devices, max_features, ratio);
+                if (got.size() == run.size() - 1) {
+                    for (size_t j = 0; j < got.size(); ++j) steps[k + j] = got[j];
+                } else {
+                    std::cerr << "Warning: batch of frames " << (first + k) << ".." << (first + e - 1)
+                              << " failed on the GPU (" << vo::last_error() << "); processing its pairs one by one\n";
+                }
             }
-            frames.push_back(img.value());
-            index.push_back(first + k);
+            k = e;
         }
-        carried.reset();
-        if (failed || frames.size() < 2) continue;
-        auto const steps = vo::process_sequence(frames, *intrinsics, max_features, ratio);
-        if (steps.size() != frames.size() - 1) {
-            std::cerr << "Warning: batch starting at frame " << first << " failed: " << vo::last_error() << "\n";
-            continue;
+        for (size_t j = 0; j < n_pairs; ++j) {
+            size_t const i = first + j;
+            if (!frames[j] || !frames[j + 1]) {
+                std::cerr << "Warning: Failed to load pair " << i << ": "
+                          << (!frames[j] ? load_error[j] : load_error[j + 1]) << "\n";
+                continue;
+            }
+            if (!steps[j]) steps[j] = single_pair(*frames[j], *frames[j + 1]);
+            account(i, *steps[j]);
         }
-        for (size_t k = 0; k < steps.size(); ++k) {
-            size_t const i = first + k;
-            if (trajectory.add_motion(steps[k].motion, loader->get_timestamp(i + 1))) ++valid_motions;
-            if ((i + 1) % 100 == 0 || i == max_pairs - 1)
-                std::cout << "  Frame " << std::setw(5) << (i + 1) << "/" << max_pairs << " | Matches: " << steps[k].matches
-                          << " | Inliers: " << steps[k].motion.inliers << (steps[k].motion.valid ? "" : " [FAILED]") << "\n";
-        }
-        carried = frames.back();
+        carried = frames[n_pairs];
+        have_carried = true;
     }
 
     std::cout << "\nProcessed " << max_pairs << " pairs, " << valid_motions << " valid motions\n";

@@ -7,6 +7,7 @@
 #include <opencv2/core.hpp>
 #include <opencv2/features2d.hpp>
 #else
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,7 @@
 #define CV_64F 6
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
 #define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
 #endif

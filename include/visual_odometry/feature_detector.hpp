@@ -28,6 +28,12 @@ struct feature_detector_config {
 [[nodiscard]] auto detect_keypoints_only(cv::Mat const& image, feature_detector_config const& config = {})
     -> std::vector<cv::KeyPoint>;
 
+// Colour copy of the image with every keypoint drawn as a circle of its size and a radius at its
+// angle (ref:include/visual_odometry/feature_detector.hpp:55, ref:src/feature_detector.cpp:29-35:
+// cv::drawKeypoints with DRAW_RICH_KEYPOINTS, green).  Visualisation only, host code; with the
+// stand-in types the circles are rasterised here, with OpenCV present the OpenCV call is made.
+[[nodiscard]] auto draw_keypoints(cv::Mat const& image, std::vector<cv::KeyPoint> const& keypoints) -> cv::Mat;
+
 // Message of the most recent GPU-side failure on this thread ("" if none).  The three
 // hot-path functions keep the reference's no-throw contract: on a device error they return
 // the empty / invalid result and leave the reason here.

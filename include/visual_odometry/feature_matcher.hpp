@@ -28,4 +28,11 @@ struct feature_matcher_config {
                                   std::span<cv::KeyPoint const> keypoints2,
                                   feature_matcher_config const& config = {}) -> match_result;
 
+// The two images side by side in colour with a line per match
+// (ref:include/visual_odometry/feature_matcher.hpp:55, ref:src/feature_matcher.cpp:44-55:
+// cv::drawMatches, green, unmatched keypoints not drawn).  Visualisation only, host code.
+[[nodiscard]] auto draw_feature_matches(cv::Mat const& image1, std::vector<cv::KeyPoint> const& keypoints1,
+                                        cv::Mat const& image2, std::vector<cv::KeyPoint> const& keypoints2,
+                                        std::vector<cv::DMatch> const& matches) -> cv::Mat;
+
 }  // namespace visual_odometry

@@ -25,4 +25,14 @@ struct sequence_step {
                                     int max_features = 2000, float ratio_threshold = 0.75f,
                                     motion_estimator_config const& config = {}) -> std::vector<sequence_step>;
 
+// The same over several GPUs of one node: `devices` lists the GPU indices; the pairs are split
+// into one contiguous block per device (the frame at a block boundary is detected by both
+// neighbours), every block runs on a host thread and context of its own, and the steps come
+// back in pair order - the same steps as the single-GPU call.  An empty list means the
+// calling thread's default device.  Calls from several host threads are serialised.
+[[nodiscard]] auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& intrinsics,
+                                    std::span<int const> devices, int max_features = 2000,
+                                    float ratio_threshold = 0.75f, motion_estimator_config const& config = {})
+    -> std::vector<sequence_step>;
+
 }  // namespace visual_odometry

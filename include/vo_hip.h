@@ -239,6 +239,22 @@ int vo_pipeline_sequence(vo_ctx* ctx, const uint8_t* imgs, int n_frames, int row
                          size_t image_stride, int max_features, float ratio, const double K[4],
                          double threshold, double confidence, int fixed_iters, vo_pair_result* results);
 
+/* The same over several GPUs of one node (the reference is a serial loop over
+ * independent pairs, ref:src/main.cpp:152-184): ctxs[k], one context per GPU
+ * created by the caller, takes the contiguous block of pairs
+ * vo_block_range(n_frames - 1, k, n_ctx, ...) on a host thread of its own - the
+ * frames of that block plus one, the boundary frame being detected by both
+ * neighbours - and the records land at their pair index, so results are those
+ * of one vo_pipeline_sequence call.  No data moves between GPUs.  Returns the
+ * first hard error (message in ctxs[0]), VO_ERR_CAPACITY if only truncations
+ * were reported. */
+int vo_pipeline_sequence_multi(vo_ctx* const* ctxs, int n_ctx, const uint8_t* imgs, int n_frames, int rows, int cols,
+                               int step, size_t image_stride, int max_features, float ratio, const double K[4],
+                               double threshold, double confidence, int fixed_iters, vo_pair_result* results);
+/* Contiguous block [*begin, *end) of n units owned by part `part` of `parts`
+ * (sizes differ by at most one).  Host arithmetic, no GPU call. */
+int vo_block_range(int n, int part, int parts, int* begin, int* end);
+
 /* --- inspection (parity tests) ---------------------------------------------------
  * Copies pyramid level `level` of image `image` of the most recent detect call
  * (blurred != 0: the 7x7 Gaussian-blurred copy the descriptors sample) to

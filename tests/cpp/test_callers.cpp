@@ -11,6 +11,10 @@
 #include <iostream>
 #include <string>
 
+#include <vector>
+
+#include <visual_odometry/feature_detector.hpp>
+#include <visual_odometry/feature_matcher.hpp>
 #include <visual_odometry/image_loader.hpp>
 #include <visual_odometry/trajectory.hpp>
 
@@ -155,7 +159,42 @@ static void loader_cases(std::string const& dir) {
     std::printf("pairs %zu\n", pairs);
 }
 
+// ref:tests/test_feature_detector.cpp:67-78 (DrawsKeypoints), ref:tests/test_feature_matcher.cpp:121-135 (DrawsMatches)
+static void draw_cases() {
+    namespace vo = visual_odometry;
+    cv::Mat a(120, 160, CV_8UC1, cv::Scalar(90)), b(120, 200, CV_8UC1, cv::Scalar(40));
+    std::vector<cv::KeyPoint> k1(3), k2(3);
+    for (int i = 0; i < 3; ++i) {
+        k1[(size_t)i].pt = cv::Point2f(30.f + 40.f * (float)i, 50.f);
+        k1[(size_t)i].size = 31.f;
+        k1[(size_t)i].angle = 45.f * (float)i;
+        k2[(size_t)i].pt = cv::Point2f(20.f + 50.f * (float)i, 70.f);
+        k2[(size_t)i].size = 7.f;
+    }
+    cv::Mat const drawn = vo::draw_keypoints(a, k1);
+    CHECK(!drawn.empty() && drawn.channels() == 3 && drawn.rows == a.rows && drawn.cols == a.cols);
+    int green = 0;
+    for (int y = 0; y < drawn.rows; ++y)
+        for (int x = 0; x < drawn.cols; ++x) {
+            unsigned char const* p = drawn.ptr<unsigned char>(y) + 3 * x;
+            green += p[0] == 0 && p[1] == 255 && p[2] == 0;
+        }
+    CHECK(green > 100);                                      // three circles of radius 15 and their radii
+    CHECK(drawn.ptr<unsigned char>(0)[0] == 90);             // untouched pixels keep the gray value
+    std::vector<cv::DMatch> m(2);
+    m[0].queryIdx = 0; m[0].trainIdx = 2;
+    m[1].queryIdx = 2; m[1].trainIdx = 0;
+    cv::Mat const side = vo::draw_feature_matches(a, k1, b, k2, m);
+    CHECK(!side.empty() && side.channels() == 3 && side.cols == a.cols + b.cols && side.rows == 120);
+    CHECK(vo::draw_keypoints(cv::Mat(), k1).empty());
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--draw") {
+        draw_cases();
+        std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
+        return failures ? 1 : 0;
+    }
     trajectory_cases();
     if (argc > 1) loader_cases(argv[1]);
     std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);

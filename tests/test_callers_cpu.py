@@ -173,3 +173,40 @@ def test_python_api_host_side(dataset, tmp_path):
     assert (k.fx, k.fy, k.cx, k.cy) == (517.3, 516.5, 318.6, 255.3) and k.camera_matrix()[0, 2] == 318.6
     with pytest.raises(RuntimeError, match="Could not open camera file"):
         api.CameraIntrinsics.load_from_yaml(tmp_path / "none.yaml")
+
+
+def test_block_range_of_the_library_equals_the_python_helper():
+    from visual_odometry_amd import capi, sharding
+    for n in (0, 1, 5, 64, 100, 65536):
+        for parts in (1, 2, 3, 8):
+            for part in range(parts):
+                assert capi.block_range(n, part, parts) == sharding.block_range(n, part, parts)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout is not present on this machine")
+def test_reference_callers_compile_and_link_unchanged(tmp_path):
+    """The reference's own callers of the hot path - its command-line tool and its benchmark
+    (ref:src/main.cpp, ref:benchmarks/benchmark_matchers.cpp) - compiled as they are against the
+    drop-in headers (stand-in OpenCV / Eigen / tl types, no OpenCV here) and linked against the
+    drop-in library: every declaration and symbol they use must exist."""
+    inc = os.path.join(ROOT, "include")
+    lib = os.path.join(ROOT, "visual_odometry_amd")
+    for src, exe in (("src/main.cpp", "ref_main"), ("benchmarks/benchmark_matchers.cpp", "ref_benchmark")):
+        out = tmp_path / exe
+        cmd = ["g++", "-std=c++20", "-O1", "-I", inc, os.path.join(REF, src), "-o", str(out), "-L", lib,
+               "-lvisual_odometry_hip", "-lvo_hip", f"-Wl,-rpath,{lib}"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        # argument handling runs without a GPU: no --images -> usage and exit code 1
+        r = subprocess.run([str(out)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "--images" in (r.stderr + r.stdout)
+
+
+def test_draw_helpers_of_the_dropin():
+    # ref:tests/test_feature_detector.cpp:67-78, ref:tests/test_feature_matcher.cpp:121-135 (host code)
+    exe = os.path.join(ROOT, "tests", "cpp", "test_callers")
+    r = subprocess.run([exe, "--draw"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -118,3 +118,39 @@ def test_benchmark_tool_json(ctx, tmp_path):
     assert js["avg_time_ms"] > 0 and js["batched_avg_time_ms"] > 0
     for key in ("total_time_ms", "avg_inliers"):
         assert key in js
+
+
+@pytest.mark.gpu
+def test_cli_one_bad_frame_costs_only_its_two_pairs(ctx, tmp_path):
+    """A frame that cannot be decoded, and one of another size, in the middle of a directory: the
+    reference skips only the pair(s) a bad frame belongs to (ref:src/main.cpp:152-158) and handles a
+    size change pair by pair; the batched tool must lose nothing else, whatever the batch size."""
+    from PIL import Image
+    a, b = synth.frame_pair(730)
+    small = synth.frame_pair(731, height=240, width=320)[0]
+    frames = [a, b, a, None, b, a, small, b, a]           # frame 3 corrupt, frame 6 of another size
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        if f is None:
+            (d / f"{i:03d}.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"garbage" * 10)
+        else:
+            Image.fromarray(f).save(d / f"{i:03d}.png")
+    cam = tmp_path / "cam.yaml"
+    cam.write_text("%YAML:1.0\n---\nfx: {}\nfy: {}\ncx: {}\ncy: {}\n".format(*K))
+    good = ctx.pipeline_sequence(np.stack([a, b, a]), 2000, K)    # records of pairs (a,b), (b,a)
+    assert good["valid"].all()
+    outs = []
+    for batch in (2, 3, 64):
+        out = tmp_path / f"traj_{batch}.json"
+        run = subprocess.run([CLI, "--images", str(d), "--camera", str(cam), "--output", str(out), "--batch", str(batch)],
+                             capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert run.stderr.count("Warning: Failed to load pair") == 2
+        assert "Failed to load pair 2" in run.stderr and "Failed to load pair 3" in run.stderr
+        # pairs 0, 1 (a,b),(b,a) and 4 (b,a) and 7 (b,a) are valid; 5 and 6 touch the small frame
+        # (unrelated content: whatever they give, they are attempted, not dropped)
+        poses = json.loads(out.read_text())["poses"]
+        assert len(poses) >= 1 + 4
+        outs.append(out.read_text())
+    assert outs[0] == outs[1] == outs[2]

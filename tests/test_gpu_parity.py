@@ -720,3 +720,25 @@ def test_host_calls_between_async_pipeline_calls(ctx, oracle):
         assert gk.tobytes() == ok.tobytes() and np.array_equal(gdesc, odesc)
         assert r1.cpu().numpy().tobytes() == ref
         assert r2.cpu().numpy().tobytes() == ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ctx,n_frames", [(2, 9), (3, 8), (4, 3)])
+def test_sequence_over_several_contexts_equals_one(ctx, n_ctx, n_frames):
+    """vo_pipeline_sequence_multi: contiguous blocks of pairs on one context and host thread each,
+    the boundary frame detected on both sides.  The box has one GPU, so the contexts all sit on
+    device 0 - the split, the overlap, the threads and the ordering are what is exercised - and
+    the records must be those of a single call, byte for byte (also with more contexts than pairs)."""
+    from visual_odometry_amd import capi
+    frames = []
+    for s in range(n_frames):
+        frames.append(synth.frame_pair(800 + s // 2)[s % 2])
+    frames = np.stack(frames)
+    want = ctx.pipeline_sequence(frames, 1500, TUM_K)
+    ctxs = [capi.Context(0) for _ in range(n_ctx)]
+    got = capi.pipeline_sequence_multi(ctxs, frames, 1500, TUM_K)
+    assert got.tobytes() == want.tobytes()
+    with pytest.raises(capi.VoError, match="listed twice"):
+        capi.pipeline_sequence_multi([ctxs[0], ctxs[0]], frames, 1500, TUM_K)
+    for c in ctxs:
+        c.close()

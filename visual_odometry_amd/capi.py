@@ -25,7 +25,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
-    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
+    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
@@ -80,6 +80,8 @@ def load():
     lib.vo_pipeline_pairs_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence_dev.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
     lib.vo_pipeline_sequence.argtypes = [vp, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
+    lib.vo_pipeline_sequence_multi.argtypes = [vp, i, vp, i, i, i, i, sz, i, f, vp, d, d, i, vp]
+    lib.vo_block_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_level.argtypes = [vp, i, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
     lib.vo_debug_fast_stats.argtypes = [vp, i, vp]
@@ -294,3 +296,26 @@ class Context:
         self._check(self.lib.vo_pipeline_sequence(self.h, _p(frames), n, h, w, w, h * w, max_features, ratio, _p(Kd),
                                                   threshold, confidence, fixed_iters, _p(out)), "vo_pipeline_sequence")
         return out
+
+
+def block_range(n, part, parts):
+    """[begin, end) of n units owned by part `part` of `parts` (vo_block_range; no GPU call)."""
+    b, e = C.c_int(), C.c_int()
+    if load().vo_block_range(int(n), int(part), int(parts), C.byref(b), C.byref(e)) != 0:
+        raise VoError("vo_block_range: bad argument")
+    return b.value, e.value
+
+
+def pipeline_sequence_multi(contexts, frames, max_features, K, ratio=0.75, threshold=1.0, confidence=0.999,
+                            fixed_iters=0):
+    """vo_pipeline_sequence over several contexts (one per GPU): host frames in, PAIR_DTYPE records of the
+    n_frames - 1 pairs out, in pair order."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    Kd = np.asarray(K, np.float64)
+    out = np.zeros(n - 1, PAIR_DTYPE)
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = load().vo_pipeline_sequence_multi(arr, len(contexts), _p(frames), n, h, w, w, h * w, max_features, ratio,
+                                           _p(Kd), threshold, confidence, fixed_iters, _p(out))
+    contexts[0]._check(rc, "vo_pipeline_sequence_multi")
+    return out

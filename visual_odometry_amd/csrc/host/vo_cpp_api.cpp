@@ -4,7 +4,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -189,10 +191,12 @@ auto match_images_orb(cv::Mat const& img1, cv::Mat const& img2, feature_detector
     return r;
 }
 
+#ifndef VO_WITH_LIGHTGLUE   // (with it, the reference's own src/image_matcher.cpp defines the factory)
 auto create_image_matcher(std::string_view name) -> image_matcher {
     if (name == "orb" || name.empty()) return orb_matcher{};
     throw std::runtime_error("Unknown matcher: " + std::string(name));
 }
+#endif
 
 auto camera_intrinsics::camera_matrix() const -> cv::Mat {
     cv::Mat m(3, 3, CV_64FC1);
@@ -251,27 +255,31 @@ auto estimate_motion(std::span<cv::Point2f const> points1, std::span<cv::Point2f
     return r;
 }
 
-auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& intrinsics, int max_features,
-                      float ratio_threshold, motion_estimator_config const& config) -> std::vector<sequence_step> {
-    std::vector<sequence_step> steps;
-    if (frames.size() < 2 || max_features <= 0) return steps;
-    int const rows = frames[0].rows, cols = frames[0].cols;
-    for (auto const& f : frames)
-        if (f.empty() || f.rows != rows || f.cols != cols || f.type() != CV_8UC1) return steps;
-    vo_ctx* c = ctx();
-    if (!c) return steps;
+namespace {
+
+// Packs the frames and checks them; on failure leaves the reason in last_error().
+bool pack_frames(std::span<cv::Mat const> frames, int max_features, std::vector<uint8_t>& packed, int& rows, int& cols) {
+    auto& t = tls();
+    if (frames.size() < 2) { t.err = "process_sequence: fewer than two frames"; return false; }
+    if (max_features <= 0) { t.err = "process_sequence: max_features must be positive"; return false; }
+    rows = frames[0].rows;
+    cols = frames[0].cols;
+    for (size_t i = 0; i < frames.size(); ++i) {
+        auto const& f = frames[i];
+        if (f.empty() || f.rows != rows || f.cols != cols || f.type() != CV_8UC1) {
+            t.err = "process_sequence: frame " + std::to_string(i) + " is empty or differs from frame 0 in size or type";
+            return false;
+        }
+    }
     size_t const image_bytes = (size_t)rows * cols;
-    std::vector<uint8_t> packed(frames.size() * image_bytes);
+    packed.resize(frames.size() * image_bytes);
     for (size_t i = 0; i < frames.size(); ++i)
         for (int r = 0; r < rows; ++r) std::memcpy(&packed[i * image_bytes + (size_t)r * cols], frames[i].ptr<uint8_t>(r), cols);
-    std::vector<vo_pair_result> rec(frames.size() - 1);
-    double const K[4] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy};
-    int const rc = vo_pipeline_sequence(c, packed.data(), (int)frames.size(), rows, cols, cols, image_bytes, max_features,
-                                        ratio_threshold, K, config.ransac_threshold, config.ransac_confidence, 0, rec.data());
-    // a truncated keypoint list (VO_ERR_CAPACITY) still yields every record: keep them, leave the
-    // message in last_error()
-    if (!ok(rc) && rc != VO_ERR_CAPACITY) return steps;
-    steps.resize(rec.size());
+    return true;
+}
+
+auto to_steps(std::vector<vo_pair_result> const& rec) -> std::vector<sequence_step> {
+    std::vector<sequence_step> steps(rec.size());
     for (size_t i = 0; i < rec.size(); ++i) {
         sequence_step& s = steps[i];
         s.keypoints1 = rec[i].n_kp1;
@@ -285,6 +293,78 @@ auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& 
         }
     }
     return steps;
+}
+
+// One context per GPU for the multi-device call, created on first use and kept for the life of
+// the process; the mutex serialises whole calls (a context serves one host thread at a time).
+struct device_pool {
+    std::mutex m;
+    std::map<int, vo_ctx*> ctx;
+    ~device_pool() {
+        for (auto& kv : ctx) vo_ctx_destroy(kv.second);
+    }
+};
+device_pool& pool() {
+    static device_pool p;
+    return p;
+}
+
+}  // namespace
+
+auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& intrinsics, int max_features,
+                      float ratio_threshold, motion_estimator_config const& config) -> std::vector<sequence_step> {
+    std::vector<uint8_t> packed;
+    int rows = 0, cols = 0;
+    if (!pack_frames(frames, max_features, packed, rows, cols)) return {};
+    vo_ctx* c = ctx();
+    if (!c) return {};
+    std::vector<vo_pair_result> rec(frames.size() - 1);
+    double const K[4] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy};
+    int const rc = vo_pipeline_sequence(c, packed.data(), (int)frames.size(), rows, cols, cols, (size_t)rows * cols,
+                                        max_features, ratio_threshold, K, config.ransac_threshold,
+                                        config.ransac_confidence, 0, rec.data());
+    // a truncated keypoint list (VO_ERR_CAPACITY) still yields every record: keep them, leave the
+    // message in last_error()
+    if (!ok(rc) && rc != VO_ERR_CAPACITY) return {};
+    return to_steps(rec);
+}
+
+auto process_sequence(std::span<cv::Mat const> frames, camera_intrinsics const& intrinsics, std::span<int const> devices,
+                      int max_features, float ratio_threshold, motion_estimator_config const& config)
+    -> std::vector<sequence_step> {
+    if (devices.empty()) return process_sequence(frames, intrinsics, max_features, ratio_threshold, config);
+    std::vector<uint8_t> packed;
+    int rows = 0, cols = 0;
+    if (!pack_frames(frames, max_features, packed, rows, cols)) return {};
+    auto& p = pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    std::vector<vo_ctx*> ctxs;
+    for (int dev : devices) {
+        auto it = p.ctx.find(dev);
+        if (it == p.ctx.end()) {
+            vo_ctx* c = nullptr;
+            int const rc = vo_ctx_create(dev, &c);
+            if (rc != VO_OK || !c) {
+                tls().err = "vo_ctx_create(device " + std::to_string(dev) + ") failed with code " + std::to_string(rc);
+                return {};
+            }
+            it = p.ctx.emplace(dev, c).first;
+        }
+        for (vo_ctx* have : ctxs)
+            if (have == it->second) {
+                tls().err = "process_sequence: device " + std::to_string(dev) + " is listed twice";
+                return {};
+            }
+        ctxs.push_back(it->second);
+    }
+    std::vector<vo_pair_result> rec(frames.size() - 1);
+    double const K[4] = {intrinsics.fx, intrinsics.fy, intrinsics.cx, intrinsics.cy};
+    int const rc = vo_pipeline_sequence_multi(ctxs.data(), (int)ctxs.size(), packed.data(), (int)frames.size(), rows, cols,
+                                              cols, (size_t)rows * cols, max_features, ratio_threshold, K,
+                                              config.ransac_threshold, config.ransac_confidence, 0, rec.data());
+    if (rc != VO_OK) tls().err = vo_last_error(ctxs[0]);
+    if (rc != VO_OK && rc != VO_ERR_CAPACITY) return {};
+    return to_steps(rec);
 }
 
 }  // namespace visual_odometry

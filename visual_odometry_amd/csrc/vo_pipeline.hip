@@ -4,6 +4,8 @@
 // reference's main loop chains them (ref:src/main.cpp:162-170).
 #include <algorithm>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "vo_internal.h"
 
@@ -190,4 +192,55 @@ extern "C" int vo_match_images(vo_ctx* c, const uint8_t* img1, const uint8_t* im
     *n_kps2 = n2;
     *n_matches = m;
     return VO_OK;
+}
+
+// Contiguous block [begin, end) of n units owned by part `part` of `parts` (sizes differ by at
+// most one, larger blocks first).
+extern "C" int vo_block_range(int n, int part, int parts, int* begin, int* end) {
+    if (n < 0 || parts <= 0 || part < 0 || part >= parts || !begin || !end) return VO_ERR_INVALID;
+    const int base = n / parts, rem = n % parts;
+    *begin = part * base + std::min(part, rem);
+    *end = *begin + base + (part < rem ? 1 : 0);
+    return VO_OK;
+}
+
+// vo_pipeline_sequence over several GPUs of one node: the reference's loop over the pairs of a
+// directory (ref:src/main.cpp:152-184) has independent iterations, so context k takes the
+// contiguous block of pairs vo_block_range(n_frames - 1, k, n_ctx) - the frames of that block
+// plus one, the frame shared with the next block being detected by both - on a host thread of
+// its own, and writes its records at their pair index.  No device-to-device traffic.
+extern "C" int vo_pipeline_sequence_multi(vo_ctx* const* ctxs, int n_ctx, const uint8_t* imgs, int n_frames, int rows,
+                                          int cols, int step, size_t image_stride, int max_features, float ratio,
+                                          const double K[4], double threshold, double confidence, int fixed_iters,
+                                          vo_pair_result* results) {
+    if (!ctxs || n_ctx <= 0) return VO_ERR_INVALID;
+    for (int k = 0; k < n_ctx; ++k)
+        if (!ctxs[k]) return VO_ERR_INVALID;
+    if (n_frames < 2 || !imgs || !results || !K)
+        return fail(ctxs[0], VO_ERR_INVALID, "vo_pipeline_sequence_multi: bad argument");
+    for (int a = 0; a < n_ctx; ++a)
+        for (int b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a] == ctxs[b])
+                return fail(ctxs[0], VO_ERR_INVALID, "vo_pipeline_sequence_multi: a context is listed twice (contexts are not thread-safe)");
+    const int n_pairs = n_frames - 1;
+    std::vector<int> rc((size_t)n_ctx, VO_OK);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n_ctx; ++k) {
+        int b = 0, e = 0;
+        vo_block_range(n_pairs, k, n_ctx, &b, &e);
+        if (e <= b) continue;   // more contexts than pairs
+        workers.emplace_back([=, &rc] {
+            rc[(size_t)k] = vo_pipeline_sequence(ctxs[k], imgs + (size_t)b * image_stride, e - b + 1, rows, cols, step,
+                                                 image_stride, max_features, ratio, K, threshold, confidence, fixed_iters,
+                                                 results + b);
+        });
+    }
+    for (auto& w : workers) w.join();
+    int out = VO_OK;
+    for (int k = 0; k < n_ctx; ++k) {
+        if (rc[(size_t)k] == VO_OK) continue;
+        if (out == VO_OK || out == VO_ERR_CAPACITY) out = rc[(size_t)k];   // a hard failure outranks a truncation report
+        if (k != 0) ctxs[0]->err = "context " + std::to_string(k) + ": " + ctxs[k]->err;
+    }
+    return out;
 }
