@@ -99,6 +99,13 @@ def dataset(tmp_path_factory):
     expect["09_photo.jpg"] = None          # JPEG: "Failed to load image"
     (d / "10_broken.png").write_bytes(b"\x89PNG\r\n\x1a\nnot really")
     expect["10_broken.png"] = None
+    # a 65-byte file whose header promises 32768 x 32768 RGBA16 pixels (8.6 GB): refused before any allocation
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 32768, 16, 6, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0" * 2)) + chunk(b"IEND", b"")
+    (d / "11_bomb.png").write_bytes(bomb)
+    expect["11_bomb.png"] = None
     (d / "notes.txt").write_text("ignored")
     (root / "rgb.txt").write_text("# timestamp filename\n1305031102.175304 rgb/00_gray8.png\n1305031102.211214 rgb/01_rgb.png\n")
     return str(d), expect

@@ -146,7 +146,15 @@ auto decode_png(std::vector<uint8_t> const& file) -> cv::Mat {
         if (ih.w <= passes[k].x0 || ih.h <= passes[k].y0 || pw == 0 || ph == 0) continue;
         raw_size += (size_t)ph * (((size_t)pw * bpp + 7) / 8 + 1);
     }
-    std::vector<uint8_t> raw(raw_size);
+    // deflate expands by at most 1032:1, so a header that promises more pixels than the compressed
+    // stream can hold is a broken (or hostile) file: refuse it before allocating anything
+    if (raw_size > idat.size() * 1032 + 64) return {};
+    std::vector<uint8_t> raw;
+    try {
+        raw.resize(raw_size);
+    } catch (std::bad_alloc const&) {
+        return {};
+    }
     uLongf got = (uLongf)raw_size;
     int const zrc = uncompress(raw.data(), &got, idat.data(), (uLong)idat.size());
     if (zrc != Z_OK || got != raw_size) return {};
