@@ -114,6 +114,13 @@ def set_five_point_charts(n):
     lib().oracle_set_five_point_charts(int(n))
 
 
+def set_variant(trig_float=False, five_point_literal=False):
+    """Study switches: descriptor rotation through libm's cosf / sinf instead of the double routines
+    rounded to float; the minimal solver as OpenCV writes it (one chart, roots with |imag| <= 1e-10,
+    no refinement, no duplicate drop).  Both off by default - the variant the GPU is pinned to."""
+    lib().oracle_set_variant(int(trig_float), int(five_point_literal))
+
+
 def five_point(x1, x2):
     x1 = np.ascontiguousarray(x1, np.float64).reshape(5, 2)
     x2 = np.ascontiguousarray(x2, np.float64).reshape(5, 2)

@@ -31,6 +31,12 @@
 #include <cstring>
 #include <vector>
 
+// Study switches (oracle_set_variant): the two places where this restatement reads OpenCV one
+// way and another reading is defensible.  Defaults are what the parity tests pin the GPU to.
+static bool g_trig_float = false;          // descriptor rotation through cosf / sinf
+static bool g_five_point_literal = false;  // OpenCV-literal minimal solver: one chart, roots kept only
+                                           // with |imag| <= 1e-10, no refinement, no duplicate drop
+
 namespace {
 
 // ---------------------------------------------------------------- helpers
@@ -394,7 +400,18 @@ void orb_descriptor(const Level& L, const KeyPoint& kp, uint8_t* desc) {
     float scale = 1.f / L.scale;
     float angle = kp.angle;
     angle *= (float)(M_PI / 180.f);
-    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    // orb.cpp writes (float)cos(angle) with a float argument; whether that resolves to the float
+    // or the double libm routine depends on the overload set in scope.  Default: the double
+    // routine rounded to float; g_trig_float: libm's cosf / sinf (study switch, see
+    // oracle_set_variant).
+    float a, b;
+    if (g_trig_float) {
+        a = cosf(angle);
+        b = sinf(angle);
+    } else {
+        a = (float)std::cos((double)angle);
+        b = (float)std::sin((double)angle);
+    }
     int cy = cv_round(kp.y * scale), cx = cv_round(kp.x * scale);
     const uint8_t* center = &L.blur[(size_t)cy * L.w + cx];
     int step = L.w;
@@ -904,7 +921,9 @@ int five_point_chart(const double* x1, const double* x2, int chart, double* Es, 
         // OpenCV keeps a root only if |imag| <= 1e-10.  Durand-Kerner is often short of
         // that on clustered roots after its 300 sweeps, so the gate here is loose and the
         // refinement below (which rejects starts that do not settle) decides instead.
-        if (std::fabs(rt.imag()) > 1e-3 * std::max(1.0, std::fabs(rt.real()))) continue;
+        if (g_five_point_literal ? std::fabs(rt.imag()) > 1e-10
+                                 : std::fabs(rt.imag()) > 1e-3 * std::max(1.0, std::fabs(rt.real())))
+            continue;
         double z1 = rt.real(), z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
         for (int j = 0; j < 3; ++j) {
@@ -920,6 +939,18 @@ int five_point_chart(const double* x1, const double* x2, int chart, double* Es, 
         if (std::fabs(xy1[2]) < 1e-10) continue;
         double xyz[3] = {xy1[0] / xy1[2], xy1[1] / xy1[2], z1};
         double Ev[9];
+        if (g_five_point_literal) {            // E from the root as it stands, unit norm
+            double nrm = 0;
+            for (int k = 0; k < 9; ++k) {
+                Ev[k] = EE[0][k] * xyz[0] + EE[1][k] * xyz[1] + EE[2][k] * xyz[2] + EE[3][k];
+                nrm += Ev[k] * Ev[k];
+            }
+            nrm = std::sqrt(nrm);
+            for (int k = 0; k < 9; ++k) Es[count * 9 + k] = Ev[k] / nrm;
+            ++count;
+            if (count == 10) break;
+            continue;
+        }
         double res = polish_model(EE, xyz, Ev);
         if (!(res <= 1e-12)) continue;         // did not settle on a solution
         bool dup = false;                      // two starts that settled on the same solution
@@ -950,7 +981,7 @@ static int g_five_point_charts = 4;
 
 int five_point(const double* x1, const double* x2, double* Es, double* dbg = nullptr) {
     int count = five_point_chart(x1, x2, 0, Es, dbg);
-    for (int c = 1; c < g_five_point_charts && count < 10; ++c) {
+    for (int c = 1; c < g_five_point_charts && count < 10 && !g_five_point_literal; ++c) {
         double more[90];
         int n = five_point_chart(x1, x2, c, more);
         for (int i = 0; i < n && count < 10; ++i) {
@@ -1235,6 +1266,12 @@ int oracle_match(const uint8_t* q, int nq, const uint8_t* t, int nt, float ratio
 
 int oracle_five_point(const double* x1, const double* x2, double* Es) { return five_point(x1, x2, Es); }
 void oracle_set_five_point_charts(int n) { g_five_point_charts = n < 1 ? 1 : n; }
+// trig_float != 0: descriptor rotation through libm's cosf / sinf; five_point_literal != 0: the
+// minimal solver as OpenCV writes it (see the switches' declarations).  Both 0 by default.
+void oracle_set_variant(int trig_float, int five_point_literal) {
+    g_trig_float = trig_float != 0;
+    g_five_point_literal = five_point_literal != 0;
+}
 
 // Same, also returning the degree-10 polynomial (dbg[0..10], ascending), the raw
 // Durand-Kerner roots (dbg[11..30] as re,im pairs) and their number (dbg[31]).

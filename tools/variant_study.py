@@ -1,0 +1,99 @@
+"""Study of the two places where the CPU restatement reads OpenCV one way and another reading is
+defensible (oracle.set_variant): (1) the descriptor rotation through cosf / sinf instead of the
+double routines rounded to float - CPU only; (2) the OpenCV-literal minimal solver (one chart,
+|imag| <= 1e-10 root gate, no refinement) against the complete, refined solution sets the GPU
+is pinned to - GPU against oracle under each setting (VO_FIVE_POINT_LITERAL), and default against
+literal.  Writes gpurun_out/variant_study.json."""
+import json
+import os
+import sys
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O
+from visual_odometry_amd import synth
+
+out = {}
+# ---- (1) trig reading, CPU only
+n_kp = n_desc_diff = n_bits = 0
+for seed in range(12):
+    img = synth.frame_pair(900 + seed)[seed & 1]
+    O.set_variant(False, False)
+    k0, d0 = O.orb_detect(img, 2000)
+    O.set_variant(True, False)
+    k1, d1 = O.orb_detect(img, 2000)
+    assert k0.tobytes() == k1.tobytes()
+    n_kp += len(k0)
+    diff = np.unpackbits(d0 ^ d1, axis=1).sum(1)
+    n_desc_diff += int(np.count_nonzero(diff))
+    n_bits += int(diff.sum())
+O.set_variant(False, False)
+out["trig_float_vs_double"] = {"images": 12, "keypoints": n_kp, "descriptors_that_differ": n_desc_diff,
+                               "bits_that_differ": n_bits}
+print(out["trig_float_vs_double"], flush=True)
+
+# ---- (2) minimal solver
+if "--cpu-only" not in sys.argv:
+    import torch  # noqa: F401
+    from visual_odometry_amd import capi
+    ctx = capi.Context(0)
+else:
+    ctx = None
+K = synth.TUM_K
+sets = []
+frames = synth.sequence(0x5EED0000, 41)
+for p in range(40):
+    sets.append(("sequence", frames[p], frames[p + 1], 1000))
+for p in range(20):
+    a, b = synth.frame_pair(0x5EED0000 + p)
+    sets.append(("dense", a, b, 2000))
+
+
+def rot_deg(R1, R2):
+    return float(np.degrees(np.arccos(np.clip((np.trace(R1.T @ R2) - 1) / 2, -1, 1))))
+
+
+stats = {"pairs": len(sets)}
+agree = {"default": 0, "literal": 0}
+changed_model = changed_iters = changed_inliers = pose_moved = 0
+worst_rot = worst_t = 0.0
+for kind, a, b, nf in sets:
+    ka, da = O.orb_detect(a, nf)
+    kb, db = O.orb_detect(b, nf)
+    qi, ti, _ = O.match(da, db)
+    p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
+    p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
+    res = {}
+    for name, lit in (("default", False), ("literal", True)):
+        O.set_variant(False, lit)
+        og, oE, om, oit, _ = O.find_essential(p1, p2, K)
+        op = O.estimate_motion(p1, p2, K)
+        res[name] = (og, oE, oit, op)
+        if ctx is not None:
+            os.environ["VO_FIVE_POINT_LITERAL"] = "1" if lit else "0"
+            gg, gE, gm, git, _ = ctx.find_essential(p1, p2, K)
+            s = 1.0 if np.sum(gE * oE) > 0 else -1.0
+            same = gg == og and git == oit and np.max(np.abs(gE - s * oE)) < (1e-8 if not lit else 1e-5)
+            agree[name] += bool(same)
+    O.set_variant(False, False)
+    os.environ["VO_FIVE_POINT_LITERAL"] = "0"
+    (g0, E0, it0, p0), (g1, E1, it1, p1_) = res["default"], res["literal"]
+    s = 1.0 if np.sum(E0 * E1) > 0 else -1.0
+    changed_model += bool(np.max(np.abs(E0 - s * E1)) > 1e-6)
+    changed_iters += it0 != it1
+    changed_inliers += g0 != g1
+    if p0["valid"] and p1_["valid"]:
+        r, t = rot_deg(p0["R"], p1_["R"]), float(np.linalg.norm(p0["t"] - p1_["t"]))
+        worst_rot, worst_t = max(worst_rot, r), max(worst_t, t)
+        pose_moved += bool(r > 0.01 or t > 1e-4)
+stats.update({"gpu_equals_oracle_default": agree["default"] if ctx else None,
+              "gpu_equals_oracle_literal": agree["literal"] if ctx else None,
+              "literal_vs_default_winning_model_differs": changed_model,
+              "literal_vs_default_iteration_count_differs": changed_iters,
+              "literal_vs_default_inlier_count_differs": changed_inliers,
+              "literal_vs_default_pose_beyond_0.01deg_or_1e-4": pose_moved,
+              "literal_vs_default_worst_rotation_deg": worst_rot, "literal_vs_default_worst_translation": worst_t})
+out["five_point_literal_vs_complete"] = stats
+print(stats, flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/variant_study.json", "w"), indent=1)

@@ -423,9 +423,9 @@ __host__ __device__ __forceinline__ void ess_constraints_dir(const double* E, co
 // the five-point problem to rounding whatever the conditioning of the
 // elimination that produced the starting point.  Returns the largest
 // constraint residual of the unit-norm result written to Eout.
-__host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout) {
+__host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout,
+                                            int kSteps = 12) {
     double E[9];
-    constexpr int kSteps = 12;
     for (int it = 0; it <= kSteps; ++it) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) E[k] = B[0][k] * x + B[1][k] * y + B[2][k] * z + B[3][k];
@@ -1019,8 +1019,10 @@ __device__ __forceinline__ void solve_front(bool active, const double* x1, const
 #else
 #define VO_TICK(k) do { } while (0)
 #endif
+// literal != 0 (study switch, VO_FIVE_POINT_LITERAL): the models are taken from the roots as they
+// stand - no refinement, no residual gate, no duplicate drop - as OpenCV's solver leaves them.
 __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, const double* __restrict__ rec0,
-                                                 double* __restrict__ Es0, int32_t* __restrict__ nm0) {
+                                                 double* __restrict__ Es0, int32_t* __restrict__ nm0, int literal = 0) {
     const int tid = threadIdx.x;
 #ifdef VO_PHASE_TIMING
     long long ticks[16];
@@ -1089,8 +1091,8 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
-            double res = polish_model_dev(EE, sx, sy, z1, Ev);
-            acc = res <= 1e-12;   // settled on a solution
+            double res = polish_model_dev(EE, sx, sy, z1, Ev, literal ? 0 : 12);
+            acc = literal ? res < 1e299 : res <= 1e-12;   // settled on a solution
             if (acc) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
@@ -1106,7 +1108,7 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
     for (int item = tid; item < total; item += BACK_THREADS) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         uint32_t bits = 0;
-        if (sh.acc[h][r]) {
+        if (sh.acc[h][r] && !literal) {
             double Ev[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) Ev[k] = sh.Ev[h][r][k];
@@ -1239,17 +1241,18 @@ __global__ __launch_bounds__(256) void merge_models_kernel(const int32_t* __rest
     }
 }
 
+
 __global__ __launch_bounds__(BACK_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
                                                                   const double* __restrict__ recs,
                                                                   double* __restrict__ models,
                                                                   int32_t* __restrict__ nmodels,
-                                                                  int32_t* __restrict__ retry_list) {
+                                                                  int32_t* __restrict__ retry_list, int literal) {
     __shared__ BackShared sh;
     const int b = blockIdx.y;
     if (st[b].done) return;
     const int h0 = blockIdx.x * HB;
     const size_t slot = (size_t)b * hr + h0;
-    solve_back_block(sh, min(HB, hr - h0), recs + slot * HYP_REC, models + slot * kMaxModels * 9, nmodels + slot);
+    solve_back_block(sh, min(HB, hr - h0), recs + slot * HYP_REC, models + slot * kMaxModels * 9, nmodels + slot, literal);
     // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
     // the count it wrote itself)
     if (retry_list && threadIdx.x < min(HB, hr - h0) && (nmodels[slot + threadIdx.x] & 1))
@@ -1330,28 +1333,46 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
 // wavefront per pair: the round's model counts are staged in LDS with coalesced loads, lane 0
 // then replays the serial loop on them (a dependent global load per step otherwise).
 constexpr int UPD_MAX_HR = 512;
-__global__ __launch_bounds__(64) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
+__global__ __launch_bounds__(128) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
                                                     const double* __restrict__ models, const int32_t* __restrict__ nmodels,
                                                     const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
                                                     int samples_stride, int next_round, int32_t* __restrict__ samples_log,
                                                     int log_cap, int32_t* __restrict__ retry_list) {
     __shared__ int32_t s_nm[UPD_MAX_HR];
     __shared__ int32_t s_cnt[UPD_MAX_HR * kMaxModels];
+    __shared__ unsigned long long s_rng;
+    __shared__ int s_drawn;
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b == 0 && lane == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
     if (stv[b].done) return;   // workgroup-uniform
     const int live = min(hr, max(stv[b].niters - h0, 0));   // hypotheses the serial loop can reach
-    for (int h = lane; h < live; h += 64) s_nm[h] = nmodels[(size_t)b * hr + h];
-    for (int i = lane; i < live * kMaxModels; i += 64) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
+    for (int h = lane; h < live; h += 128) s_nm[h] = nmodels[(size_t)b * hr + h];
+    for (int i = lane; i < live * kMaxModels; i += 128) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
     if (samples_log) {
         const int32_t* src = samples + (size_t)b * samples_stride;
         const int lim = min(live, log_cap - h0);
-        for (int i = lane; i < lim * 5; i += 64) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
+        for (int i = lane; i < lim * 5; i += 128) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
     }
+    if (lane == 0) s_drawn = 0;
     __syncthreads();
-    if (lane != 0) return;
-    RState s = stv[b];
+    // Two serial jobs side by side, one lane of each wavefront: the bookkeeping replay below, and
+    // the next round's samples.  The sample stream does not depend on the round's outcome - only
+    // how many are needed does, and the iteration bound can only shrink during the replay - so
+    // the second wavefront draws for the bound as it stood before the replay; surplus sets are
+    // never used, and a pair that ends in this round never looks at the stream again.
+    if (lane == 64 && next_round > 0) {
+        RState d = stv[b];
+        const int want = min(next_round, d.niters - (h0 + hr));
+        if (want > 0) {
+            draw_samples(d, samples + (size_t)b * samples_stride, want);
+            s_rng = d.rng;
+            s_drawn = 1;
+        }
+    }
+    RState s;
     int h = 0, best_h = -1, best_k = 0;
+    if (lane == 0) {
+    s = stv[b];
     for (; h < hr; ++h) {
         if (h0 + h >= s.niters) break;
         int nm = s_nm[h];
@@ -1373,14 +1394,13 @@ __global__ __launch_bounds__(64) void update_kernel(RState* __restrict__ stv, in
         const double* E = models + (((size_t)b * hr + best_h) * kMaxModels + best_k) * 9;
         for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
     }
-    if (h < hr || h0 + hr >= s.niters) {
-        s.done = 1;
-    } else if (next_round > 0) {
-        draw_samples(s, samples + (size_t)b * samples_stride, min(next_round, s.niters - (h0 + hr)));
-    } else {
-        s.done = 1;
+    if (h < hr || h0 + hr >= s.niters || next_round <= 0) s.done = 1;
     }
-    stv[b] = s;
+    __syncthreads();
+    if (lane == 0) {
+        if (s_drawn) s.rng = s_rng;
+        stv[b] = s;
+    }
 }
 
 // ------------------------------------------------------------------ pose recovery
@@ -1753,6 +1773,10 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     P.confidence = confidence;
     P.fixed_iters = fixed_iters;
     const int HR = 512;   // largest round
+    // study switch (read at every call): the minimal solver without refinement, second chart or
+    // duplicate drop, to measure what those add
+    const char* lit_env = getenv("VO_FIVE_POINT_LITERAL");
+    const int literal = lit_env && atoi(lit_env) != 0;
     int rc;
     int nm = std::max(n_max, 1);
     if ((rc = ensure(c, c->r_state, (size_t)batch * sizeof(RState)))) return rc;
@@ -1794,24 +1818,27 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
         hipLaunchKernelGGL(solve_back_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
-                           models, nmodels, retry_list);
-        // second chart for the few hypotheses with an odd number of models: small fixed grids that
-        // stride over the list (its count is zeroed again by update_kernel)
+                           models, nmodels, literal ? nullptr : retry_list, literal);
+        // Second chart for the few hypotheses with an odd number of models: small fixed grids that
+        // stride over the list (its count is zeroed again by update_kernel).  (Running this pass on
+        // a stream of its own beside the scoring of the first pass's models, and scoring what it
+        // adds afterwards, measured no faster: the chain is short against the scoring kernel and
+        // the two event hand-offs per round cost what the overlap gains.)
         static const bool no_retry = getenv("VO_NO_RETRY") != nullptr;   // measurement aid
-        if (!no_retry) {
-        hipLaunchKernelGGL(retry_front_kernel, dim3(256), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
-                           (const int32_t*)retry_list, recs);
-        hipLaunchKernelGGL(retry_back_kernel, dim3(64), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
-                           (const double*)recs, models2, nmodels2);
-        hipLaunchKernelGGL(merge_models_kernel, dim3(16), dim3(256), 0, s, (const int32_t*)retry_list, 0, models, nmodels,
-                           (const double*)models2, (const int32_t*)nmodels2);
+        if (!no_retry && !literal) {
+            hipLaunchKernelGGL(retry_front_kernel, dim3(256), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
+                               (const int32_t*)retry_list, recs);
+            hipLaunchKernelGGL(retry_back_kernel, dim3(64), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
+                               (const double*)recs, models2, nmodels2);
+            hipLaunchKernelGGL(merge_models_kernel, dim3(16), dim3(256), 0, s, (const int32_t*)retry_list, 0, models, nmodels,
+                               (const double*)models2, (const int32_t*)nmodels2);
         }
         t_end_on(c, VO_T_RANSAC_SOLVE, s);
         t_begin_on(c, VO_T_RANSAC_SCORE, s);
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         t_end_on(c, VO_T_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(64), 0, s, st, batch, P, h0, hr, models, nmodels,
+        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(128), 0, s, st, batch, P, h0, hr, models, nmodels,
                            counts, samples, HR * 5, next, d_samples, samples_cap, retry_list);
         h0 += hr;
     }
