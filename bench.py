@@ -188,6 +188,7 @@ class Runner:
         self.ress = [torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in ctxs]
         self.counter = 0
         self.H, self.W = H, W
+        self.scene_counters = True
 
     def call(self, ctx, res):
         c = self.cfg
@@ -217,11 +218,14 @@ class Runner:
         a second pass, because the split brackets sit inside the chain's bracket) and the FAST
         stage's scene counters."""
         ctx, res, capi = self.ctxs[0], self.ress[0], self.capi
-        ctx.fast_stats(True)          # (the scene counters are global atomics: counted in a call of their own)
-        self.call(ctx, res)
-        ctx.sync()
-        stats = ctx.fast_stats(False)
-        stats["calls"] = 1
+        if self.scene_counters:
+            ctx.fast_stats(True)      # (the scene counters are global atomics: counted in a call of their own)
+            self.call(ctx, res)
+            ctx.sync()
+            stats = ctx.fast_stats(False)
+            stats["calls"] = 1
+        else:                         # counter-collection runs: no launch that differs from the timed ones
+            stats = {"pixels": 0, "pretest_pass": 0, "corners": 0, "candidates": 0, "calls": 0}
         ctx.set_timing(True)
         for _ in range(reps):
             self.call(ctx, res)
@@ -311,6 +315,10 @@ def main():
     ap.add_argument("--no-sequence", action="store_true")
     ap.add_argument("--no-aux-scene", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-scene-counters", action="store_true",
+                    help="skip the one call that counts pretest passes / corners with global atomics (its FAST "
+                         "launches are several times slower than normal ones and would skew per-kernel averages "
+                         "of a profiler run)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -341,6 +349,7 @@ def main():
     ctxs = [capi.Context(local_rank) for _ in range(n_streams)]
     ctx = ctxs[0]
     run = Runner(torch, dist, capi, ctxs, cfg, frames, P, K, world)
+    run.scene_counters = not args.no_scene_counters
 
     for _ in range(max(args.warmup, n_streams)):
         run.step()

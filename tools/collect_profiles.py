@@ -2,7 +2,7 @@
 """Copies the evidence of the last GPU runs from gpurun_out/ into profiles/ (bench line, rocprofv3
 kernel statistics, HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes).
 
-    python tools/collect_profiles.py r01_f
+    python tools/collect_profiles.py r02
 """
 import collections
 import csv
@@ -31,6 +31,15 @@ d = json.load(open(os.path.join(R, "gpurun_out/bench_final.json")))
 shutil.copy(os.path.join(R, "gpurun_out/bench_final.json"), os.path.join(R, f"profiles/{tag}_bench_default.json"))
 stats = latest("gpurun_out/prof_default/**/*kernel_stats.csv")
 shutil.copy(stats, os.path.join(R, f"profiles/{tag}_kernel_stats_default.csv"))
+for w in ("c3", "c5", "c1", "sparse"):        # tools/profile_workload.sh runs of the other workloads
+    try:
+        shutil.copy(latest(f"gpurun_out/prof_{w}/**/*kernel_stats.csv"), os.path.join(R, f"profiles/{tag}_kernel_stats_{w}.csv"))
+        shutil.copy(os.path.join(R, f"gpurun_out/prof_{w}.json"), os.path.join(R, f"profiles/{tag}_bench_{w}.json"))
+    except (IndexError, OSError) as e:
+        print("no profile of", w, e)
+for w in ("c2", "c5"):                        # tools/serial_kernel_times.sh
+    if os.path.exists(os.path.join(R, f"gpurun_out/serial_{w}.txt")):
+        shutil.copy(os.path.join(R, f"gpurun_out/serial_{w}.txt"), os.path.join(R, f"profiles/{tag}_serial_kernel_times_{w}.txt"))
 print("bench", round(d["value"]), "pairs/s,", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "ms by events")
 for r in list(csv.DictReader(open(stats)))[:8]:
     print("  ", r["Name"][:44].ljust(44), r["Calls"], float(r["AverageNs"]) / 1e6, "ms", r["Percentage"], "%")

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Exclusive per-kernel times: rocprofv3 kernel trace of a short bench run, reduced to the bench's
 # own serial pass (three pipeline calls with every group bracketed, one stream, a sync between calls).
+# Extra arguments go to bench.py (e.g. --workload c5_1080p_10000kp_4096hyp).
 export TMPDIR=/tmp
 R=$PWD
 rm -rf $R/gpurun_out/prof_serial
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-hamming --no-sequence --warmup 1 --steps 2 > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-hamming --no-sequence --no-aux-scene --no-dropin --warmup 1 --steps 2 "$@" > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
 python3 - $(ls $R/gpurun_out/prof_serial/*/*kernel_trace.csv | head -1) <<'PY'
 import csv, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
@@ -14,10 +15,10 @@ for r in rows:
 tot = 0.0
 out = []
 for k, v in per.items():
-    if len(v) % 6:
+    if len(v) % 10:
         continue
-    n = len(v) // 6                      # launches per pipeline call; calls 1..3 are the serial pass
-    ser = v[n:4 * n]
+    n = len(v) // 10                     # launches per pipeline call: 1 warm-up, 1 scene-counter call, then the
+    ser = v[2 * n:5 * n]                 # serial pass (calls 2..4), 3 calls of the RANSAC split, 2 timed steps
     out.append((sum(ser) / 3e3, n, k))
     tot += sum(ser) / 3e3
 for us, n, k in sorted(out, reverse=True):
