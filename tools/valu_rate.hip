@@ -99,6 +99,12 @@ KERNEL(k_dot4, "v_dot4_u32_u8 %0, %1, %2, %0")
 KERNEL(k_dot2_u16, "v_dot2_u32_u16 %0, %1, %2, %0")
 KERNEL(k_sad_u8, "v_sad_u8 %0, %1, %2, %0")
 KERNEL(k_msad_u8, "v_msad_u8 %0, %1, %2, %0")
+KERNEL(k_lerp_u8, "v_lerp_u8 %0, %0, %1, %2")
+KERNEL(k_lerp_u8_0, "v_lerp_u8 %0, %0, %1, 0")
+KERNEL(k_lerp_u8_sgpr, "v_lerp_u8 %0, %0, s20, 0")
+KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80")
+KERNEL(k_min3_u32, "v_min3_u32 %0, %0, %1, %2")
+KERNEL(k_max3_u32, "v_max3_u32 %0, %0, %1, %2")
 KERNEL(k_sub_sdwa, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 KERNEL(k_cvt_f32_ubyte, "v_cvt_f32_ubyte1 %0, %1")
 KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %2")
@@ -166,7 +172,7 @@ int main() {
 #define RUN(k) run(#k, k, 1, d)
     RUN(k_add); RUN(k_pk_min_i16); RUN(k_pk_max_u16); RUN(k_pk_add_i16); RUN(k_pk_sub_u16); RUN(k_pk_lshr_b16);
     RUN(k_perm); RUN(k_alignbit); RUN(k_alignbyte); RUN(k_mad_u24); RUN(k_mul_u24); RUN(k_mul_lo); RUN(k_bfe);
-    RUN(k_bcnt); RUN(k_mbcnt); RUN(k_dot4); RUN(k_dot2_u16); RUN(k_sad_u8); RUN(k_msad_u8); RUN(k_sub_sdwa);
+    RUN(k_bcnt); RUN(k_mbcnt); RUN(k_dot4); RUN(k_dot2_u16); RUN(k_sad_u8); RUN(k_lerp_u8); RUN(k_lerp_u8_0); RUN(k_lerp_u8_sgpr); RUN(k_bitop3); RUN(k_min3_u32); RUN(k_max3_u32); RUN(k_msad_u8); RUN(k_sub_sdwa);
     RUN(k_and_or); RUN(k_lshl_add); RUN(k_add3); RUN(k_bfi); RUN(k_min_i32); RUN(k_min3_i32); RUN(k_med3_i32);
     RUN(k_cvt_f32_ubyte); RUN(k_fma_f32); RUN(k_rndne); RUN(k_cvt_i32_f32); RUN(k_lshlrev_b64ish); RUN(k_add);
     RUN(k_and); RUN(k_or); RUN(k_xor); RUN(k_sub); RUN(k_lshl); RUN(k_ashr); RUN(k_max_u32); RUN(k_mov); RUN(k_add_f32);

@@ -175,56 +175,42 @@ constexpr int FS_W = FP_W, FS_H = FT_H + 2;   // score tile (1-px halo), logical
                                               // so that a queue entry (byte offset into the pixel tile) also addresses the score
 constexpr int FQ_N = FS_H * (FT_W + 2);     // positions whose score is needed
 
-__device__ __forceinline__ bool has_arc9(unsigned m) {
-    m |= m << 16;
-    unsigned a = m & (m >> 1);
-    a &= a >> 2;
-    a &= a >> 4;
-    a &= m >> 8;
-    return (a & 0xFFFFu) != 0;
-}
+constexpr int FP_N = FP_H * FP_W;            // bytes of the pixel tile; its inverted copy (255 - p) follows it
+constexpr int FQ1_N = 2 * FQ_N;              // a position can enter the first queue once per polarity
 
-// the 16 ring pixels (Bresenham circle of radius 3, OpenCV's order); returns the centre
-__device__ __forceinline__ int ring_pixels(const uint8_t* p, int* r) {
+// Largest minimum over the sixteen 9-arcs of the ring (Bresenham circle of radius 3) around
+// p, minus the centre: > thr iff the pixel is a FAST-9/16 corner whose ring is brighter, and
+// then cornerScore<16> is that value minus 1.  Read from the inverted copy of the tile the
+// same code answers for a ring that is darker (255 - r against 255 - centre).  An arc's
+// minimum is min3 of three 3-runs: 16 + 16 three-operand minima and 8 three-operand maxima.
+__device__ __forceinline__ int ring_arc_contrast(const uint8_t* p) {
     constexpr int P = FP_W;
     const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
                          -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
+    int r[16], m3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) r[k] = (int)p[off[k]];
-    return (int)p[0];
+    const int v = (int)p[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m3[i] = min(min(r[i], r[(i + 1) & 15]), r[(i + 2) & 15]);
+    int best = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const int a = min(min(m3[i], m3[(i + 3) & 15]), m3[(i + 6) & 15]);
+        const int b = min(min(m3[i + 1], m3[(i + 4) & 15]), m3[(i + 7) & 15]);
+        best = max(max(best, a), b);
+    }
+    return best - v;
 }
 
-// FAST-9/16 score of a pixel known to be a corner: max over 9-arcs of the arc's minimum
-// contrast (bright or dark), minus 1 - what cornerScore<16> returns.  Both polarities in one
-// ladder of packed 16-bit operations: every ring pixel r becomes the pair (d, -d) =
-// (256 - r, r) + (centre - 256, -centre), the first pair being r * 0xFFFF + 256 (no borrow:
-// 256 - r >= 1); the low half of the result is then the largest arc minimum of d and the high
-// half that of -d.
-typedef short pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int corner_score_packed(const uint8_t* p) {
-    constexpr int P = FP_W;
-    const int off[16] = {3 * P,      3 * P + 1,  2 * P + 2,  P + 3,  3,       -P + 3,     -2 * P + 2, -3 * P + 1,
-                         -3 * P,     -3 * P - 1, -2 * P - 2, -P - 3, -3,      P - 3,      2 * P - 2,  3 * P - 1};
-    const int v = p[0];
-    const pk16 vc = {(short)(v - 256), (short)(-v)};
-    pk16 d[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t rp = __umul24((uint32_t)p[off[k]], 0xFFFFu) + 256u;
-        d[k] = __builtin_bit_cast(pk16, rp) + vc;
-    }
-    pk16 m2[16], m4[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m2[i] = __builtin_elementwise_min(d[i], d[(i + 1) & 15]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m4[i] = __builtin_elementwise_min(m2[i], m2[(i + 2) & 15]);
-    pk16 best = {-1000, -1000};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const pk16 m8 = __builtin_elementwise_min(m4[i], m4[(i + 4) & 15]);
-        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, d[(i + 8) & 15]));
-    }
-    return max((int)best.x, (int)best.y) - 1;
+// LDS fetch-and-add issued as written.  (atomicAdd under `if (lane == 0)` is rewritten by the
+// compiler's atomic optimiser into a count of the active lanes, a multiply and a broadcast:
+// some ten vector instructions for a single-lane add.)
+__device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v) {
+    uint32_t r;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a), "v"(v) : "memory");
+    return r;
 }
 
 // Appends `val` for the lanes with pass == true to an LDS queue: one atomic per wavefront.
@@ -232,27 +218,30 @@ __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, 
     unsigned long long m = __ballot(pass);
     if (m == 0) return;
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+    if (lane == 0) base = lds_fetch_add(cnt, (uint32_t)__popcll(m));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (pass) q[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base))] = val;
 }
 
-// One launch over every level's 64x32 tiles of the 31-px interior.  Three filters of
-// growing cost, each feeding the next through a wavefront-compacted LDS queue so that the
-// expensive stages run on dense wavefronts:
-//   1. four cardinal ring pixels: a 9-arc always contains two adjacent cardinals;
-//   2. the full 16-pixel ring masks and the 9-contiguous test;
-//   3. the corner score (min/max ladder), written to an LDS score tile;
+// One launch over every level's 64x32 tiles of the 31-px interior.  Two filters, the first
+// feeding the second through a wavefront-compacted LDS queue so that the expensive one runs
+// on dense wavefronts:
+//   1. four cardinal ring pixels, per polarity: a 9-arc always contains two adjacent cardinals;
+//   2. the largest 9-arc minimum of the ring in the polarity the pre-test passed (both in
+//      the rare case that both did): it decides the corner test and is the corner score, so
+//      the ring is read once; scores go to an LDS score tile, corners to a second queue;
 // then 3x3 non-max suppression, the border filter and one global atomic per tile.
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
                                                    uint32_t tile_first, uint32_t ntiles, uint32_t tile_magic,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
                                                    unsigned long long* __restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) uint8_t px[FP_H * FP_W];
+    __shared__ __attribute__((aligned(16))) uint8_t px[2 * FP_N];   // the tile, then 255 - tile
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
-    __shared__ uint16_t q1[FQ_N], q2[FQ_N];
-    __shared__ uint32_t list[FT_W * FT_H / 4];
+    __shared__ __attribute__((aligned(16))) uint16_t q1[FQ1_N];
+    __shared__ uint16_t q2[FQ_N];
+    uint32_t* const list = reinterpret_cast<uint32_t*>(q1);   // the first queue is dead when the list is built
+    static_assert(sizeof(uint16_t) * FQ1_N >= sizeof(uint32_t) * (FT_W * FT_H / 4), "the candidate list fits the first queue");
     __shared__ uint32_t n1, n2, nlist, gbase;
     __shared__ uint32_t colmask[32];
 
@@ -281,13 +270,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     constexpr int g0 = cx0 >> 2, ng = ((cx0 + FT_W + 1) >> 2) - g0 + 1;   // dword groups that hold score columns
     const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
     if (tid < ng) {
-        // pre-test result bits (9, 10, 25, 26: pixels 0..3) of the group's columns that are score
+        // pre-test result bits (7, 15, 23, 31: pixels 0..3) of the group's columns that are score
         // columns 0 .. lim_x: the same for every row, so looked up instead of recomputed per group
         const int lim_x = min(FT_W + 1, max_sx);
         const int sx0 = 4 * (g0 + tid) - cx0;
         const int lo = max(-sx0, 0), hi = min(lim_x - sx0 + 1, 4);
         const uint32_t nib = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-        colmask[tid] = ((nib & 3u) << 9) | ((nib & 12u) << 23);
+        colmask[tid] = ((nib & 1u) << 7) | ((nib & 2u) << 14) | ((nib & 4u) << 21) | ((nib & 8u) << 28);
     }
 
     bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
@@ -303,6 +292,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 int y = min(max(y0 - 4 + r, 0), L.h - 1);
                 uint32_t v = *reinterpret_cast<const uint32_t*>(base + ((uint32_t)__mul24(y, pitch) + col));
                 *reinterpret_cast<uint32_t*>(&px[r * FP_W + 4 * c]) = v;
+                *reinterpret_cast<uint32_t*>(&px[FP_N + r * FP_W + 4 * c]) = ~v;
             }
         }
     } else {
@@ -310,113 +300,99 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             int r = i / FP_W, c = i - r * FP_W;
             int y = min(max(y0 - 4 + r, 0), L.h - 1);
             int x = min(ax0 + c, L.w - 1);
-            px[i] = base[(size_t)y * pitch + x];
+            const uint8_t v = base[(size_t)y * pitch + x];
+            px[i] = v;
+            px[FP_N + i] = (uint8_t)~v;
         }
     }
     __syncthreads();
 
     // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed,
-    // four horizontally adjacent pixels per lane.  The even and the odd bytes of a dword sit
-    // in 16-bit fields; with K = 511 - thr in both fields, (centre + K) - ring has bit 9 of a
-    // field set iff centre - ring > thr and ring + (K - centre) iff ring - centre > thr (no
-    // carry crosses a field: all values stay in [236, 746]).  A 9-arc contains two adjacent
-    // cardinals, i.e. (S | N) & (E | W) for one polarity.
+    // four horizontally adjacent pixels per lane, one per byte.  v_lerp_u8 averages bytes
+    // without carries between them: x = (a + (255 - b)) >> 1 (b read from the inverted copy)
+    // and then (x + 128 - thr / 2) >> 1 has bit 7 set iff a - b > thr.  A 9-arc contains two
+    // adjacent cardinals, i.e. (S | N) & (E | W) for one polarity.  A queue entry is the byte
+    // offset of the pixel in the tile copy its polarity is scored on: the plain one for a
+    // brighter ring, the inverted one (+ FP_N) for a darker ring.
     {
+        static_assert(kFastThr % 2 == 0 && kFastThr < 254, "the two-step average tests a - b >= thr + 1 exactly for even thr");
         constexpr int PD = FP_W / 4;   // dwords per LDS row
         const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
+        const uint32_t* ix32 = px32 + FP_N / 4;
         const int lim_y = min(FS_H - 1, max_sy);
-        constexpr uint32_t KK = (uint32_t)(511 - kFastThr) * 0x00010001u, EV = 0x00FF00FFu, FL = 0x02000200u;
+        constexpr uint32_t KT = (uint32_t)(128 - kFastThr / 2) * 0x01010101u;
+        auto above = [](uint32_t a, uint32_t inv_b) -> uint32_t {   // bit 7 of a byte: a - b > thr
+            return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, inv_b, 0u), KT, 0u);
+        };
+        // slot = wave-uniform base + number of passing lanes below this one (v_mbcnt pair)
+        auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
+            return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
+        };
         for (int i0 = 0; i0 < ng * FS_H; i0 += 256) {
             const int i = i0 + tid;
             const int sy = i / ng, gk = i - sy * ng, gi = g0 + gk;
-            uint32_t T = 0;   // bits 9, 10, 25, 26: pixels 0..3 of the group pass
+            uint32_t TD = 0, TB = 0;   // bits 7, 15, 23, 31: pixels 0..3 of the group pass (darker / brighter ring)
             if (sy <= lim_y) {
                 const int idx = (sy + 3) * PD + gi;
                 const uint32_t C = px32[idx], Lw = px32[idx - 1], Rw = px32[idx + 1];
                 const uint32_t S = px32[idx + 3 * PD], N = px32[idx - 3 * PD];
+                const uint32_t Ci = ix32[idx], Li = ix32[idx - 1], Ri = ix32[idx + 1];
+                const uint32_t Si = ix32[idx + 3 * PD], Ni = ix32[idx - 3 * PD];
                 const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1), E = __builtin_amdgcn_alignbyte(Rw, C, 3);
-                const uint32_t Ce = C & EV, Co = (C >> 8) & EV;
-                const uint32_t be = Ce + KK, de = KK - Ce, bo = Co + KK, dn = KK - Co;
-                const uint32_t Se = S & EV, So = (S >> 8) & EV, Ne = N & EV, No = (N >> 8) & EV;
-                const uint32_t Ee = E & EV, Eo = (E >> 8) & EV, We = W & EV, Wo = (W >> 8) & EV;
-                const uint32_t pe = (((be - Se) | (be - Ne)) & ((be - Ee) | (be - We))) |
-                                    (((Se + de) | (Ne + de)) & ((Ee + de) | (We + de)));
-                const uint32_t po = (((bo - So) | (bo - No)) & ((bo - Eo) | (bo - Wo))) |
-                                    (((So + dn) | (No + dn)) & ((Eo + dn) | (Wo + dn)));
-                T = ((pe & FL) | ((po & FL) << 1)) & colmask[gk];
+                const uint32_t Wi = __builtin_amdgcn_alignbyte(Ci, Li, 1), Ei = __builtin_amdgcn_alignbyte(Ri, Ci, 3);
+                const uint32_t cm = colmask[gk];
+                TD = (above(C, Si) | above(C, Ni)) & (above(C, Ei) | above(C, Wi)) & cm;
+                TB = (above(S, Ci) | above(N, Ci)) & (above(E, Ci) | above(W, Ci)) & cm;
             }
-            const unsigned long long m0 = __ballot(T & (1u << 9)), m1 = __ballot(T & (1u << 10));
-            const unsigned long long m2 = __ballot(T & (1u << 25)), m3 = __ballot(T & (1u << 26));
+            const uint32_t T = TD | TB;
+            const unsigned long long m0 = __ballot(T & 0x80u), m1 = __ballot(T & 0x8000u);
+            const unsigned long long m2 = __ballot(T & 0x800000u), m3 = __ballot(T & 0x80000000u);
             const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
             const uint32_t tot = c0 + c1 + c2 + (uint32_t)__popcll(m3);
             if (tot == 0) continue;   // wave-uniform
             uint32_t qb = 0;
-            if (lane == 0) qb = atomicAdd(&n1, tot);
+            if (lane == 0) qb = lds_fetch_add(&n1, tot);
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            // slot = wave-uniform base + number of passing lanes below this one (v_mbcnt pair)
-            auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
-                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
-            };
-            // queue entry: byte offset of the pixel in the LDS pixel tile
-            const uint16_t pos = (uint16_t)((sy + 3) * FP_W + 4 * gi);
-            if (T & (1u << 9)) q1[slot(m0, qb)] = pos;
-            if (T & (1u << 10)) q1[slot(m1, qb + c0)] = (uint16_t)(pos + 1);
-            if (T & (1u << 25)) q1[slot(m2, qb + c0 + c1)] = (uint16_t)(pos + 2);
-            if (T & (1u << 26)) q1[slot(m3, qb + c0 + c1 + c2)] = (uint16_t)(pos + 3);
+            const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
+            // one entry per passing pixel: the darker-ring copy if that polarity passed, else the plain one
+            if (T & 0x80u) q1[slot(m0, qb)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FP_N) + pos);
+            if (T & 0x8000u) q1[slot(m1, qb + c0)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FP_N) + (pos + 1));
+            if (T & 0x800000u) q1[slot(m2, qb + c0 + c1)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FP_N) + (pos + 2));
+            if (T & 0x80000000u) q1[slot(m3, qb + c0 + c1 + c2)] = (uint16_t)(__umul24(TD >> 31, FP_N) + (pos + 3));
+            // pixels that passed in both polarities (saddle-like neighbourhoods, about one in a
+            // hundred entries): a second entry for the brighter-ring polarity
+            const uint32_t both = TD & TB;
+            if (__ballot(both != 0)) {
+                wave_push(both & 0x80u, (uint16_t)pos, q1, &n1, lane);
+                wave_push(both & 0x8000u, (uint16_t)(pos + 1), q1, &n1, lane);
+                wave_push(both & 0x800000u, (uint16_t)(pos + 2), q1, &n1, lane);
+                wave_push(both & 0x80000000u, (uint16_t)(pos + 3), q1, &n1, lane);
+            }
         }
     }
     __syncthreads();
 
-    // stage 2: full ring test
-    const uint32_t c1 = n1;
-    for (uint32_t i0 = 0; i0 < c1; i0 += 256) {
-        uint32_t i = i0 + tid;
-        bool pass = false;
-        uint16_t pos = 0;
-        if (i < c1) {
-            pos = q1[i];
-            int r[16];
-            const int v = ring_pixels(&px[pos], r);
-            // ring masks through the sign bit: mask = (mask << 1) | sign(thr -+ (centre - ring))
-            // is one add and one v_alignbit per ring pixel and polarity (the reversed bit order
-            // keeps arcs contiguous)
-            int kb = kFastThr - v, kd = kFastThr + v;
-            // (opaque to the optimiser, which otherwise re-associates kb + r into (r - v) + thr:
-            // one instruction more per ring pixel)
-            asm volatile("" : "+v"(kb), "+v"(kd));
-            unsigned bright = 0, dark = 0;
-            // the 32 plain adds as one run (they issue faster in runs), then the 32 v_alignbit
-            unsigned sb[16], sd[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                sb[k] = (unsigned)(kb + r[k]);
-                sd[k] = (unsigned)(kd - r[k]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                bright = __builtin_amdgcn_alignbit(bright, sb[k], 31);
-                dark = __builtin_amdgcn_alignbit(dark, sd[k], 31);
-            }
-            // a ring pixel is in at most one of the masks, so only the one with nine or more
-            // bits can hold an arc: one arc test instead of two
-            bright &= 0xFFFFu;
-            dark &= 0xFFFFu;
-            pass = has_arc9(__popc(bright) >= 9 ? bright : dark);
-        }
-        wave_push(pass, pos, q2, &n2, lane);
-    }
-    __syncthreads();
-
-    // stage 3: corner scores (score (sy, sx) lives at the pixel's tile offset minus sc_shift)
+    // stage 2: the ring's largest 9-arc minimum against the centre, in the entry's polarity:
+    // corner test and corner score at once (score (sy, sx) lives at the pixel's offset in the
+    // plain tile minus sc_shift; at most one polarity of a pixel is a corner)
     constexpr int sc_shift = 3 * FP_W + cx0;
     static_assert(FS_W == FP_W, "one offset addresses both tiles");
-    const uint32_t c2 = n2;
-    for (uint32_t i = tid; i < c2; i += 256) {
-        const uint16_t pos = q2[i];
-        sc[pos - sc_shift] = (uint8_t)corner_score_packed(&px[pos]);
+    const uint32_t c1 = n1;
+    for (uint32_t i0 = 0; i0 < c1; i0 += 256) {
+        const uint32_t i = i0 + tid;
+        bool pass = false;
+        uint32_t pos = 0;
+        if (i < c1) {
+            const uint32_t e = q1[i];
+            const int best = ring_arc_contrast(&px[e]);
+            pos = e >= (uint32_t)FP_N ? e - (uint32_t)FP_N : e;
+            pass = best > kFastThr;
+            if (pass) sc[pos - sc_shift] = (uint8_t)(best - 1);
+        }
+        wave_push(pass, (uint16_t)pos, q2, &n2, lane);
     }
     __syncthreads();
+    const uint32_t c2 = n2;
 
     // 3x3 non-max suppression + border filter on the interior (only corners need the look-up)
     for (uint32_t i = tid; i < c2; i += 256) {
@@ -1506,12 +1482,15 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         launch_fast(s, 0, tiles0);
         t_end(c, VO_T_FAST);
     }
+    // The upper levels' launch waits for level 0's: two FAST launches side by side only halve each
+    // other's share of the vector ALUs (same step time within 0.3 %), and each launch's event
+    // bracket then measures that launch, not the pair.
+    if (fast0_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_fast0, 0));
     if (tiles_up > 0) {
         t_begin(c, VO_T_FAST);
         launch_fast(s, tiles0, tiles_up);
         t_end(c, VO_T_FAST);
     }
-    if (fast0_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_fast0, 0));
     // The blur needs only the pyramid, candidate selection and orientation are mostly latency
     // (LDS sorts, scattered window reads): the blur runs beside them on the auxiliary stream, which
     // is in order behind FAST on level 0; it additionally waits for the main stream (resize chain
