@@ -778,29 +778,36 @@ constexpr int BACK_THREADS = 512;   // eight wavefronts: one sweep covers a leve
 constexpr int HYP_REC = 88;   // doubles: flag, cf[11], bm[3][13], EE[4][9], one pad
 constexpr int PIECES = 11;    // at most ten roots of the next derivative -> eleven pieces
 
-struct BackShared {
+struct RootsShared {             // the nine derivative levels
     double cf[HB][11];
     double list[HB][2][12];      // the two alternating root lists
     double px[HB][PIECES];       // bracketed root of a piece
     double bound[HB];            // root bound R of the current level
-    double Ev[HB][kMaxModels][9];
     uint8_t ptype[HB][12];       // per piece: 1 left end is an exact zero, 2 bracketed root,
                                  // 4 right end is a touching extremum
-    uint8_t acc[HB][12];         // candidate settled on a solution
-    uint16_t close[HB][12];      // bit m: candidate m < r settled within 1e-7 of candidate r
-    uint16_t kept[HB];           // candidates that become models
     uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
     int16_t np[HB];              // roots in the current list
     uint8_t levels[HB];          // 1: the hypothesis runs the nine levels
     int total;
-#ifdef VO_PHASE_TIMING
-    int dbg_max[11], dbg_sum[11], dbg_n[11], dbg_smax[11], dbg_items[11];
-#endif
+};
+struct ModelsShared {            // roots -> refined, distinct essential matrices
+    double Ev[HB][kMaxModels][9];
+    uint8_t acc[HB][12];         // candidate settled on a solution
+    uint16_t close[HB][12];      // bit m: candidate m < r settled within 1e-7 of candidate r
+    uint16_t kept[HB];           // candidates that become models
+    uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
+    int16_t np[HB];              // roots (candidates) of the hypothesis
+    int total;
+};
+struct BackShared {              // both stages in one workgroup (second-chart pass, debug entry)
+    RootsShared r;
+    ModelsShared m;
 };
 
 // Numbers the work items of the workgroup: hypothesis h offers cnt items.  Called by the
 // first wavefront (lane = hypothesis); the map is valid after the next barrier.
-__device__ __forceinline__ void number_items(BackShared& sh, int h, int cnt) {
+template <class SH>
+__device__ __forceinline__ void number_items(SH& sh, int h, int cnt) {
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -815,14 +822,11 @@ __device__ __forceinline__ void number_items(BackShared& sh, int h, int cnt) {
 // One derivative level (degree DEG) for the whole workgroup: list `si` holds the roots of the
 // next derivative, the roots of this one go to list 1 - si (ascending).
 template <int DEG>
-__device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
+__device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
     const int tid = threadIdx.x;
     if (tid < 64) number_items(sh, tid, sh.levels[tid] ? sh.np[tid] + 1 : 0);
     __syncthreads();
     const int total = sh.total;
-#ifdef VO_PHASE_TIMING
-    if (tid == 0) sh.dbg_items[DEG] = total;
-#endif
     for (int item = tid; item < total; item += BACK_THREADS) {
         const int h = sh.map[item] & 0xFF, g = sh.map[item] >> 8;
         const int np = sh.np[h];
@@ -875,9 +879,6 @@ __device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
             if (fp != 0.0 && ((fp < 0) != inf_neg)) {
                 double step = 1e-3 * fmax(1.0, fabs(p));
                 for (int it = 0; it < 64; ++it) {
-#ifdef VO_PHASE_TIMING
-                    atomicMax(&sh.dbg_smax[DEG], it + 1);
-#endif
                     double x = p + dir * step;
                     if (fabs(x) > R) x = dir * R;
                     double fx = horner<DEG>(d, x);
@@ -912,13 +913,7 @@ __device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
                 // refined afterwards, so 1e-10 (1e-12 on the last level) relative is enough;
                 // pieces that converge linearly (a root next to an extremum) stop at 40 steps.
                 constexpr double tol = DEG < 10 ? 1e-10 : 1e-12;
-#ifdef VO_PHASE_TIMING
-                int its_dbg = 0;
-#endif
                 for (int it = 0; it < 40; ++it) {
-#ifdef VO_PHASE_TIMING
-                    ++its_dbg;
-#endif
                     if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
                         dxold = dx;
                         dx = 0.5 * (xh - xl);
@@ -934,9 +929,6 @@ __device__ __forceinline__ void roots_level_block(BackShared& sh, int si) {
                     if (f == 0.0) break;
                     if (f < 0.0) xl = x; else xh = x;
                 }
-#ifdef VO_PHASE_TIMING
-                atomicMax(&sh.dbg_max[DEG], its_dbg); atomicAdd(&sh.dbg_sum[DEG], its_dbg); atomicAdd(&sh.dbg_n[DEG], 1);
-#endif
             }
             sh.px[h][g] = x;
         }
@@ -1012,23 +1004,16 @@ __device__ __forceinline__ void solve_front(bool active, const double* x1, const
     rec[0] = ok ? 1.0 : 0.0;
 }
 
-// Back end for up to HB hypotheses (records rec0 + h * HYP_REC, h < count): writes the models
-// of hypothesis h to Es0 + h * kMaxModels * 9 and their number to nm0[h].
-#ifdef VO_PHASE_TIMING
-#define VO_TICK(k) do { if (threadIdx.x == 0) ticks[k] = clock64(); } while (0)
-#else
-#define VO_TICK(k) do { } while (0)
-#endif
-// literal != 0 (study switch, VO_FIVE_POINT_LITERAL): the models are taken from the roots as they
-// stand - no refinement, no residual gate, no duplicate drop - as OpenCV's solver leaves them.
-__device__ __forceinline__ void solve_back_block(BackShared& sh, int count, const double* __restrict__ rec0,
-                                                 double* __restrict__ Es0, int32_t* __restrict__ nm0, int literal = 0) {
+// Back end for up to HB hypotheses (records rec0 + h * HYP_REC, h < count), in two stages that
+// are separate kernels in the RANSAC rounds: the root stage needs some 100 vector registers
+// and little LDS, the model stage 244 registers (the null-space basis and the reduced
+// constraints of a candidate stay in registers through the refinement) - fused, the root stage
+// ran at the model stage's occupancy of one 512-lane workgroup per CU.
+//
+// Stage 1: real roots of the hypotheses' degree-10 polynomials; on return sh.list[h][1][0..np[h])
+// holds them in ascending order.
+__device__ __forceinline__ void roots_block(RootsShared& sh, int count, const double* __restrict__ rec0) {
     const int tid = threadIdx.x;
-#ifdef VO_PHASE_TIMING
-    long long ticks[16];
-    if (tid < 11) { sh.dbg_max[tid] = 0; sh.dbg_sum[tid] = 0; sh.dbg_n[tid] = 0; sh.dbg_smax[tid] = 0; sh.dbg_items[tid] = 0; }
-#endif
-    VO_TICK(0);
     if (tid < HB) {
         const int h = tid;
         const double* rec = rec0 + (size_t)h * HYP_REC;
@@ -1056,22 +1041,26 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
         sh.levels[h] = run ? 1 : 0;
     }
     __syncthreads();
-    VO_TICK(1);
     roots_level_block<2>(sh, 0);
-    VO_TICK(2);
     roots_level_block<3>(sh, 1);
     roots_level_block<4>(sh, 0);
-    VO_TICK(3);
     roots_level_block<5>(sh, 1);
     roots_level_block<6>(sh, 0);
-    VO_TICK(4);
     roots_level_block<7>(sh, 1);
     roots_level_block<8>(sh, 0);
-    VO_TICK(5);
     roots_level_block<9>(sh, 1);
-    VO_TICK(6);
-    roots_level_block<10>(sh, 0);   // the roots end up in list 1
-    VO_TICK(7);
+    roots_level_block<10>(sh, 0);   // the roots end up in list 1, their number in np
+}
+
+// Stage 2: the roots become models.  roots[h * roots_stride + r], r < sh.np[h] (set by the caller,
+// visible after a barrier); writes the models of hypothesis h to Es0 + h * kMaxModels * 9 and
+// their number to nm0[h].
+// literal != 0 (study switch, VO_FIVE_POINT_LITERAL): the models are taken from the roots as they
+// stand - no refinement, no residual gate, no duplicate drop - as OpenCV's solver leaves them.
+__device__ __forceinline__ void models_block(ModelsShared& sh, int count, const double* __restrict__ rec0,
+                                             const double* roots, int roots_stride, double* __restrict__ Es0,
+                                             int32_t* __restrict__ nm0, int literal) {
+    const int tid = threadIdx.x;
     // ---- one lane per candidate: start values, refinement, acceptance
     if (tid < 64) number_items(sh, tid, sh.np[tid]);
     __syncthreads();
@@ -1079,7 +1068,7 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
     for (int item = tid; item < total; item += BACK_THREADS) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         const double* rec = rec0 + (size_t)h * HYP_REC;
-        const double z1 = sh.list[h][1][r];
+        const double z1 = roots[(size_t)h * roots_stride + r];
         double EE[4][9], bm[3][13], Ev[9], sx, sy;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -1101,7 +1090,6 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
         sh.acc[h][r] = acc ? 1 : 0;
     }
     __syncthreads();
-    VO_TICK(8);
     // Two starts that settled on the same solution count once: in root order, a candidate
     // falls if a kept earlier one is within 1e-7 (either sign).  The comparisons run one
     // lane per candidate, the ordered decision is bit arithmetic by one lane per hypothesis.
@@ -1144,18 +1132,15 @@ __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, cons
 #pragma unroll
         for (int k = 0; k < 9; ++k) o[k] = sh.Ev[h][r][k];
     }
-#ifdef VO_PHASE_TIMING
-    VO_TICK(9);
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 3) {
-        int items = sh.total;
-        printf("back: load %lld L2 %lld L3-4 %lld L5-6 %lld L7-8 %lld L9 %lld L10 %lld polish %lld dedupe %lld cand %d\n",
-               ticks[1] - ticks[0], ticks[2] - ticks[1], ticks[3] - ticks[2], ticks[4] - ticks[3], ticks[5] - ticks[4],
-               ticks[6] - ticks[5], ticks[7] - ticks[6], ticks[8] - ticks[7], ticks[9] - ticks[8], items);
-        for (int D = 2; D <= 10; ++D)
-            printf("  deg %d items %d brackets %d max_its %d mean_its %.1f search_max %d\n", D, sh.dbg_items[D], sh.dbg_n[D],
-                   sh.dbg_max[D], sh.dbg_n[D] ? (double)sh.dbg_sum[D] / sh.dbg_n[D] : 0.0, sh.dbg_smax[D]);
-    }
-#endif
+}
+
+// Both stages in one workgroup.
+__device__ __forceinline__ void solve_back_block(BackShared& sh, int count, const double* __restrict__ rec0,
+                                                 double* __restrict__ Es0, int32_t* __restrict__ nm0, int literal = 0) {
+    roots_block(sh.r, count, rec0);
+    if (threadIdx.x < HB) sh.m.np[threadIdx.x] = sh.r.np[threadIdx.x];
+    __syncthreads();
+    models_block(sh.m, count, rec0, &sh.r.list[0][1][0], 2 * 12, Es0, nm0, literal);
 }
 
 __global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restrict__ st, const double* __restrict__ m,
@@ -1242,21 +1227,43 @@ __global__ __launch_bounds__(256) void merge_models_kernel(const int32_t* __rest
 }
 
 
-__global__ __launch_bounds__(BACK_THREADS) void solve_back_kernel(const RState* __restrict__ st, int hr,
-                                                                  const double* __restrict__ recs,
-                                                                  double* __restrict__ models,
-                                                                  int32_t* __restrict__ nmodels,
-                                                                  int32_t* __restrict__ retry_list, int literal) {
-    __shared__ BackShared sh;
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(BACK_THREADS) void solve_roots_kernel(const RState* __restrict__ st, int hr,
+                                                                   const double* __restrict__ recs,
+                                                                   double* __restrict__ roots,
+                                                                   int32_t* __restrict__ nroots) {
+    __shared__ RootsShared sh;
+    const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
-    const int h0 = blockIdx.x * HB;
+    const int h0 = blockIdx.x * HB, count = min(HB, hr - h0);
     const size_t slot = (size_t)b * hr + h0;
-    solve_back_block(sh, min(HB, hr - h0), recs + slot * HYP_REC, models + slot * kMaxModels * 9, nmodels + slot, literal);
+    roots_block(sh, count, recs + slot * HYP_REC);
+    for (int i = tid; i < count * kMaxModels; i += BACK_THREADS) {
+        const int h = i / kMaxModels, k = i - h * kMaxModels;
+        if (k < sh.np[h]) roots[(slot + h) * kMaxModels + k] = sh.list[h][1][k];
+    }
+    if (tid < count) nroots[slot + tid] = sh.np[tid];
+}
+
+__global__ __launch_bounds__(BACK_THREADS) void solve_models_kernel(const RState* __restrict__ st, int hr,
+                                                                    const double* __restrict__ recs,
+                                                                    const double* __restrict__ roots,
+                                                                    const int32_t* __restrict__ nroots,
+                                                                    double* __restrict__ models,
+                                                                    int32_t* __restrict__ nmodels,
+                                                                    int32_t* __restrict__ retry_list, int literal) {
+    __shared__ ModelsShared sh;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (st[b].done) return;
+    const int h0 = blockIdx.x * HB, count = min(HB, hr - h0);
+    const size_t slot = (size_t)b * hr + h0;
+    if (tid < HB) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
+    __syncthreads();
+    models_block(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels, models + slot * kMaxModels * 9,
+                 nmodels + slot, literal);
     // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
     // the count it wrote itself)
-    if (retry_list && threadIdx.x < min(HB, hr - h0) && (nmodels[slot + threadIdx.x] & 1))
-        retry_list[1 + atomicAdd(&retry_list[0], 1)] = (int32_t)(slot + threadIdx.x);
+    if (retry_list && tid < count && (nmodels[slot + tid] & 1))
+        retry_list[1 + atomicAdd(&retry_list[0], 1)] = (int32_t)(slot + tid);
 }
 
 __global__ __launch_bounds__(BACK_THREADS) void retry_back_kernel(const int32_t* __restrict__ retry_list,
@@ -1787,6 +1794,8 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if ((rc = ensure(c, c->r_models2, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_nmodels2, (size_t)batch * HR * 4))) return rc;
     if ((rc = ensure(c, c->r_retry, ((size_t)batch * HR + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->r_roots, (size_t)batch * HR * kMaxModels * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->r_nroots, (size_t)batch * HR * 4))) return rc;
     if ((rc = ensure(c, c->r_best, (size_t)batch * HR * HYP_REC * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
     RState* st = (RState*)c->r_state.p;
@@ -1797,6 +1806,8 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     double* models2 = (double*)c->r_models2.p;
     int32_t* nmodels2 = (int32_t*)c->r_nmodels2.p;
     int32_t* retry_list = (int32_t*)c->r_retry.p;
+    double* roots = (double*)c->r_roots.p;
+    int32_t* nroots = (int32_t*)c->r_nroots.p;
     double* recs = (double*)c->r_best.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
 
@@ -1817,8 +1828,11 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         t_begin_on(c, VO_T_RANSAC_SOLVE, s);
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
-        hipLaunchKernelGGL(solve_back_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
-                           models, nmodels, literal ? nullptr : retry_list, literal);
+        hipLaunchKernelGGL(solve_roots_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs, roots,
+                           nroots);
+        hipLaunchKernelGGL(solve_models_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
+                           (const double*)roots, (const int32_t*)nroots, models, nmodels, literal ? nullptr : retry_list,
+                           literal);
         // Second chart for the few hypotheses with an odd number of models: small fixed grids that
         // stride over the list (its count is zeroed again by update_kernel).  (Running this pass on
         // a stream of its own beside the scoring of the first pass's models, and scoring what it
