@@ -418,18 +418,18 @@ __host__ __device__ __forceinline__ void ess_constraints_dir(const double* E, co
         }
 }
 
-// Four Gauss-Newton steps on (x,y,z) for E = x*B0 + y*B1 + z*B2 + B3 against
-// the ten constraints, so that every model returned is the exact solution of
-// the five-point problem to rounding whatever the conditioning of the
-// elimination that produced the starting point.  Returns the largest
-// constraint residual of the unit-norm result written to Eout.
-__host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout,
-                                            int kSteps = 12) {
-    double E[9];
-    for (int it = 0; it <= kSteps; ++it) {
+// Gauss-Newton on (x,y,z) for E = x*B0 + y*B1 + z*B2 + B3 against the ten constraints, so
+// that every model returned is the exact solution of the five-point problem to rounding
+// whatever the conditioning of the elimination that produced the starting point.
+// polish_steps takes at most `steps` steps and returns true once the iteration is over
+// (converged: the last step moved nothing; or the normal equations are singular), so that
+// it can be resumed: any split of the step budget gives the result of one uninterrupted run.
+constexpr int kPolishSteps = 12;
+__host__ __device__ bool polish_steps(const double (*B)[9], double& x, double& y, double& z, int steps) {
+    for (int it = 0; it < steps; ++it) {
+        double E[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) E[k] = B[0][k] * x + B[1][k] * y + B[2][k] * z + B[3][k];
-        if (it == kSteps) break;
         double f[10], J0[10], J1[10], J2[10];
         ess_constraints(E, f);
         ess_constraints_dir(E, B[0], J0);
@@ -446,15 +446,22 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
         n00 += lam; n11 += lam; n22 += lam;
         double c00 = n11 * n22 - n12 * n12, c01 = n01 * n22 - n12 * n02, c02 = n01 * n12 - n11 * n02;
         double det = n00 * c00 - n01 * c01 + n02 * c02;
-        if (!(fabs(det) > 0)) break;
+        if (!(fabs(det) > 0)) return true;
         double inv = 1.0 / det;
         double d0 = (g0 * c00 - n01 * (g1 * n22 - n12 * g2) + n02 * (g1 * n12 - n11 * g2)) * inv;
         double d1 = (n00 * (g1 * n22 - n12 * g2) - g0 * c01 + n02 * (n01 * g2 - g1 * n02)) * inv;
         double d2 = (n00 * (n11 * g2 - g1 * n12) - n01 * (n01 * g2 - g1 * n02) + g0 * c02) * inv;
         x -= d0; y -= d1; z -= d2;
-        // converged: one more pass only rebuilds E from the final (x,y,z)
-        if (fmax(fabs(d0), fmax(fabs(d1), fabs(d2))) <= 1e-14 * fmax(1.0, fmax(fabs(x), fmax(fabs(y), fabs(z))))) it = kSteps - 1;
+        if (fmax(fabs(d0), fmax(fabs(d1), fabs(d2))) <= 1e-14 * fmax(1.0, fmax(fabs(x), fmax(fabs(y), fabs(z))))) return true;
     }
+    return false;
+}
+
+// The unit-norm model of (x,y,z) in Eout; returns its largest constraint residual.
+__host__ __device__ double polish_finish(const double (*B)[9], double x, double y, double z, double* Eout) {
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = B[0][k] * x + B[1][k] * y + B[2][k] * z + B[3][k];
     double nrm = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) nrm += E[k] * E[k];
@@ -467,6 +474,12 @@ __host__ __device__ double polish_model_dev(const double (*B)[9], double x, doub
 #pragma unroll
     for (int k = 0; k < 10; ++k) r = fmax(r, fabs(f[k]));
     return r;
+}
+
+__host__ __device__ double polish_model_dev(const double (*B)[9], double x, double y, double z, double* Eout,
+                                            int kSteps = kPolishSteps) {
+    polish_steps(B, x, y, z, kSteps);
+    return polish_finish(B, x, y, z, Eout);
 }
 
 // x1, x2: 5 normalised point pairs (x,y).  Writes up to 10 unit-norm
@@ -790,18 +803,25 @@ struct RootsShared {             // the nine derivative levels
     uint8_t levels[HB];          // 1: the hypothesis runs the nine levels
     int total;
 };
+constexpr int HBM = 96;           // hypotheses per workgroup of the model stage on its own: 4.4 candidates each on
+                                  // average, 420 of the 512 lanes busy (64 hypotheses leave 45 % of them idle, and at
+                                  // 244 registers per lane nothing else is resident to use the slots)
+template <int NH>
 struct ModelsShared {            // roots -> refined, distinct essential matrices
-    double Ev[HB][kMaxModels][9];
-    uint8_t acc[HB][12];         // candidate settled on a solution
-    uint16_t close[HB][12];      // bit m: candidate m < r settled within 1e-7 of candidate r
-    uint16_t kept[HB];           // candidates that become models
-    uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
-    int16_t np[HB];              // roots (candidates) of the hypothesis
+    double Ev[NH][kMaxModels][9];
+    uint8_t acc[NH][12];         // candidate settled on a solution
+    uint16_t close[NH][12];      // bit m: candidate m < r settled within 1e-7 of candidate r
+    uint16_t kept[NH];           // candidates that become models
+    uint16_t map[NH * PIECES];   // work item -> hypothesis | index << 8
+    int16_t np[NH];              // roots (candidates) of the hypothesis
+    uint16_t strag[NH * kMaxModels];   // candidates whose refinement goes into the second pass (map entries)
+    int nstrag;
+    int wsum;                    // candidates of the first 64 hypotheses
     int total;
 };
 struct BackShared {              // both stages in one workgroup (second-chart pass, debug entry)
     RootsShared r;
-    ModelsShared m;
+    ModelsShared<HB> m;
 };
 
 // Numbers the work items of the workgroup: hypothesis h offers cnt items.  Called by the
@@ -817,6 +837,32 @@ __device__ __forceinline__ void number_items(SH& sh, int h, int cnt) {
     const int off = incl - cnt;
     for (int g = 0; g < cnt; ++g) sh.map[off + g] = (uint16_t)(h | (g << 8));
     if (h == 63) sh.total = incl;
+}
+
+// The same for up to 128 hypotheses with sh.np[h] items each; called by the whole workgroup,
+// the map is valid on return.
+template <int NH, class SH>
+__device__ __forceinline__ void number_items_wide(SH& sh) {
+    static_assert(NH <= 128, "two wavefronts number the items");
+    const int tid = threadIdx.x;
+    int cnt = 0, incl = 0;
+    if (tid < 128) {
+        cnt = tid < NH ? sh.np[tid] : 0;
+        incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if (tid == 63) sh.wsum = incl;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int off = incl - cnt + (tid >= 64 ? sh.wsum : 0);
+        for (int g = 0; g < cnt; ++g) sh.map[off + g] = (uint16_t)(tid | (g << 8));
+        if (tid == 127) sh.total = off + cnt;
+    }
+    __syncthreads();
 }
 
 // One derivative level (degree DEG) for the whole workgroup: list `si` holds the roots of the
@@ -1057,18 +1103,26 @@ __device__ __forceinline__ void roots_block(RootsShared& sh, int count, const do
 // their number to nm0[h].
 // literal != 0 (study switch, VO_FIVE_POINT_LITERAL): the models are taken from the roots as they
 // stand - no refinement, no residual gate, no duplicate drop - as OpenCV's solver leaves them.
-__device__ __forceinline__ void models_block(ModelsShared& sh, int count, const double* __restrict__ rec0,
+template <int NH>
+__device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, const double* __restrict__ rec0,
                                              const double* roots, int roots_stride, double* __restrict__ Es0,
                                              int32_t* __restrict__ nm0, int literal) {
     const int tid = threadIdx.x;
     // ---- one lane per candidate: start values, refinement, acceptance
-    if (tid < 64) number_items(sh, tid, sh.np[tid]);
-    __syncthreads();
+    number_items_wide<NH>(sh);
     const int total = sh.total;
+    // Refinement in two passes: nearly every candidate converges within kFirstSteps steps, but
+    // one in a few dozen does not (a spurious root wanders until the step budget is spent), and
+    // a wavefront runs as long as its slowest lane.  Candidates still moving after the first pass
+    // are collected (their (x,y,z) parked in the model slot they will fill) and finished by
+    // densely packed lanes.
+    constexpr int kFirstSteps = 4;
+    if (tid == 0) sh.nstrag = 0;
+    __syncthreads();
     for (int item = tid; item < total; item += BACK_THREADS) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         const double* rec = rec0 + (size_t)h * HYP_REC;
-        const double z1 = roots[(size_t)h * roots_stride + r];
+        double z1 = roots[(size_t)h * roots_stride + r];
         double EE[4][9], bm[3][13], Ev[9], sx, sy;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -1080,14 +1134,39 @@ __device__ __forceinline__ void models_block(ModelsShared& sh, int count, const 
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
-            double res = polish_model_dev(EE, sx, sy, z1, Ev, literal ? 0 : 12);
-            acc = literal ? res < 1e299 : res <= 1e-12;   // settled on a solution
-            if (acc) {
+            if (literal || polish_steps(EE, sx, sy, z1, kFirstSteps)) {
+                double res = polish_finish(EE, sx, sy, z1, Ev);
+                acc = literal ? res < 1e299 : res <= 1e-12;   // settled on a solution
+                if (acc) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
+                    for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
+                }
+            } else {
+                sh.Ev[h][r][0] = sx;
+                sh.Ev[h][r][1] = sy;
+                sh.Ev[h][r][2] = z1;
+                sh.strag[atomicAdd(&sh.nstrag, 1)] = sh.map[item];
             }
         }
         sh.acc[h][r] = acc ? 1 : 0;
+    }
+    __syncthreads();
+    const int nstrag = sh.nstrag;
+    for (int i = tid; i < nstrag; i += BACK_THREADS) {
+        const int h = sh.strag[i] & 0xFF, r = sh.strag[i] >> 8;
+        const double* rec = rec0 + (size_t)h * HYP_REC;
+        double EE[4][9], Ev[9];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
+        double sx = sh.Ev[h][r][0], sy = sh.Ev[h][r][1], z1 = sh.Ev[h][r][2];
+        polish_steps(EE, sx, sy, z1, kPolishSteps - kFirstSteps);
+        if (polish_finish(EE, sx, sy, z1, Ev) <= 1e-12) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
+            sh.acc[h][r] = 1;
+        }
     }
     __syncthreads();
     // Two starts that settled on the same solution count once: in root order, a candidate
@@ -1115,7 +1194,7 @@ __device__ __forceinline__ void models_block(ModelsShared& sh, int count, const 
         sh.close[h][r] = (uint16_t)bits;
     }
     __syncthreads();
-    if (tid < HB && tid < count) {
+    if (tid < NH && tid < count) {
         const int h = tid, nr = sh.np[h];
         uint32_t kept = 0;
         for (int r = 0; r < nr; ++r)
@@ -1227,7 +1306,9 @@ __global__ __launch_bounds__(256) void merge_models_kernel(const int32_t* __rest
 }
 
 
-__global__ __launch_bounds__(BACK_THREADS) void solve_roots_kernel(const RState* __restrict__ st, int hr,
+// (six wavefronts per SIMD = three workgroups per CU: the stage is a chain of short dependent
+// passes between barriers, so what hides its latency is other workgroups; 80 registers suffice)
+__global__ __launch_bounds__(BACK_THREADS, 6) void solve_roots_kernel(const RState* __restrict__ st, int hr,
                                                                    const double* __restrict__ recs,
                                                                    double* __restrict__ roots,
                                                                    int32_t* __restrict__ nroots) {
@@ -1251,12 +1332,12 @@ __global__ __launch_bounds__(BACK_THREADS) void solve_models_kernel(const RState
                                                                     double* __restrict__ models,
                                                                     int32_t* __restrict__ nmodels,
                                                                     int32_t* __restrict__ retry_list, int literal) {
-    __shared__ ModelsShared sh;
+    __shared__ ModelsShared<HBM> sh;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
-    const int h0 = blockIdx.x * HB, count = min(HB, hr - h0);
+    const int h0 = blockIdx.x * HBM, count = min(HBM, hr - h0);
     const size_t slot = (size_t)b * hr + h0;
-    if (tid < HB) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
+    if (tid < HBM) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
     __syncthreads();
     models_block(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels, models + slot * kMaxModels * 9,
                  nmodels + slot, literal);
@@ -1830,7 +1911,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                            h0, hr, recs);
         hipLaunchKernelGGL(solve_roots_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs, roots,
                            nroots);
-        hipLaunchKernelGGL(solve_models_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
+        hipLaunchKernelGGL(solve_models_kernel, dim3((hr + HBM - 1) / HBM, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
                            (const double*)roots, (const int32_t*)nroots, models, nmodels, literal ? nullptr : retry_list,
                            literal);
         // Second chart for the few hypotheses with an odd number of models: small fixed grids that
