@@ -317,6 +317,22 @@ def test_find_essential_fixed_hypothesis_count(ctx, oracle, fixed):
     assert gg == og and np.array_equal(gm, om)
 
 
+@pytest.mark.parametrize("n", [6, 9, 15, 16, 17, 24, 40, 64, 200])
+def test_sample_stream_with_few_points(ctx, oracle, n):
+    # Few points make repeated indices inside a 5-subset frequent (the generator's rejection rule);
+    # below 16 points one lane draws the plain way, from 16 on the stream is generated by 64 lanes
+    # that jump ahead in the multiply-with-carry recurrence; at 16 and 17 points a round of 512 sets
+    # needs more draws than are kept and ends the plain way.  700 fixed hypotheses = two rounds.
+    p1, p2 = _matched_points(oracle, 27, 1000)
+    sel = np.random.default_rng(n).choice(len(p1), n, replace=False)
+    p1, p2 = p1[sel], p2[sel]
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, TUM_K, fixed_iters=700)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, TUM_K, fixed_iters=700)
+    assert git == oit == 700
+    assert np.array_equal(gsamp, osamp)
+    assert gg == og and np.array_equal(gm, om)
+
+
 @pytest.mark.parametrize("name", ["forward", "rotation"])
 def test_reference_motion_scenes(ctx, oracle, name):
     # ref:tests/test_motion_estimator.cpp:61-102 plus agreement with the oracle and the ground truth

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <mutex>
 
 #include "vo_internal.h"
 
@@ -1417,75 +1418,273 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     }
 }
 
-// Sequential RANSAC bookkeeping over one round, then the next round's samples.  One
-// wavefront per pair: the round's model counts are staged in LDS with coalesced loads, lane 0
-// then replays the serial loop on them (a dependent global load per step otherwise).
+// RANSAC bookkeeping over one round, then the next round's samples: one workgroup per pair.
+// Both are serial by definition - the loop keeps the first model that beats every earlier one
+// and shrinks its iteration bound as it goes; the samples come off one cv::RNG stream with
+// rejection of repeated indices - and one lane replaying them took 190 us per 512-hypothesis
+// round.  What is serial in fact is much less:
+//  * a model changes the state only if it beats the best so far, and the bound is a monotone
+//    function of the best count, so the replay reduces to a prefix maximum over the hypotheses'
+//    best counts (one wavefront) and a serial walk over the few strict improvements;
+//  * cv::RNG is a multiply-with-carry generator: with b = 2^32 and p = a b - 1 its 64-bit state
+//    obeys s' = s / b (mod p), so the state k draws ahead is s b^-k mod p and b^-k mod p is what the
+//    generator makes of the state 1 in k steps (d_mwc_jump, filled once per device).  The lanes
+//    of one wavefront jump to the start of their 48-draw chunk and run the recurrence side by
+//    side; all lanes reduce the draws modulo n and mark the stream positions whose next five
+//    values are distinct; one lane then only walks set starts (a bit test per set, the rejection
+//    loop where the bit is clear) and all lanes write the sets out.
 constexpr int UPD_MAX_HR = 512;
-__global__ __launch_bounds__(128) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
-                                                    const double* __restrict__ models, const int32_t* __restrict__ nmodels,
-                                                    const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
-                                                    int samples_stride, int next_round, int32_t* __restrict__ samples_log,
-                                                    int log_cap, int32_t* __restrict__ retry_list) {
-    __shared__ int32_t s_nm[UPD_MAX_HR];
+constexpr int UPD_T = 256;
+constexpr int UPD_CHUNK = 48, UPD_RAW = 64 * UPD_CHUNK;   // draws kept per round: 5 per set and room for repeats
+constexpr unsigned long long kMwcA = 4164903690ull, kMwcP = (kMwcA << 32) - 1ull;
+__device__ unsigned long long d_mwc_jump[64];   // the generator applied UPD_CHUNK * j times to the state 1
+
+// x * y mod p by long division of the 128-bit product (once per lane and round)
+__device__ unsigned long long mwc_mulmod(unsigned long long x, unsigned long long y) {
+    const unsigned long long hi = __umul64hi(x, y), lo = x * y;
+    unsigned long long rem = 0;
+    for (int i = 127; i >= 0; --i) {
+        const unsigned long long bit = i >= 64 ? (hi >> (i - 64)) & 1ull : (lo >> i) & 1ull;
+        const bool carry = (rem >> 63) != 0;
+        rem = (rem << 1) | bit;
+        if (carry || rem >= kMwcP) rem -= kMwcP;
+    }
+    return rem;
+}
+
+// One 5-subset by the generator's rejection rule from reduced draws v[pos...]; returns the position
+// after it, or -1 if the draws run out at `limit`.
+__device__ __forceinline__ int take_set(const uint16_t* v, int pos, int limit, int* idx) {
+    for (int i = 0; i < 5; ++i) {
+        bool dup = true;
+        int x = 0;
+        while (dup) {
+            if (pos >= limit) return -1;
+            x = v[pos++];
+            dup = false;
+            for (int k = 0; k < i; ++k) dup |= idx[k] == x;
+        }
+        idx[i] = x;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
+                                                      const double* __restrict__ models, const int32_t* __restrict__ nmodels,
+                                                      const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
+                                                      int samples_stride, int next_round, int32_t* __restrict__ samples_log,
+                                                      int log_cap, int32_t* __restrict__ retry_list) {
+    __shared__ int32_t s_nm[UPD_MAX_HR];     // models of a hypothesis that take part
     __shared__ int32_t s_cnt[UPD_MAX_HR * kMaxModels];
+    __shared__ int32_t s_hb[UPD_MAX_HR];     // a hypothesis' best count
+    __shared__ uint8_t s_hk[UPD_MAX_HR];     // and the first model that reaches it
+    __shared__ uint8_t s_imp[64];            // per lane of the first wavefront: which of its 8 hypotheses improve on all before
+    __shared__ uint32_t s_raw[UPD_RAW];
+    __shared__ uint16_t s_val[UPD_RAW];                 // draws modulo n (only used for n < 65536)
+    __shared__ unsigned long long s_w5[UPD_RAW / 64];   // bit p: the five values from position p on are distinct
+    __shared__ unsigned long long s_ck[65];             // generator state at the start of chunk j
+    __shared__ uint16_t s_off[UPD_MAX_HR];              // stream position of a set's first draw
     __shared__ unsigned long long s_rng;
-    __shared__ int s_drawn;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b == 0 && lane == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
+    __shared__ int s_drawn, s_stop, s_plain, s_sets, s_end;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b == 0 && tid == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
     if (stv[b].done) return;   // workgroup-uniform
-    const int live = min(hr, max(stv[b].niters - h0, 0));   // hypotheses the serial loop can reach
-    for (int h = lane; h < live; h += 128) s_nm[h] = nmodels[(size_t)b * hr + h];
-    for (int i = lane; i < live * kMaxModels; i += 128) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
+    const int n = stv[b].n, niters0 = stv[b].niters, exact5 = stv[b].exact5;
+    const int live = min(hr, max(niters0 - h0, 0));   // hypotheses the serial loop can reach
+    for (int h = tid; h < UPD_MAX_HR; h += UPD_T) {
+        int nm = h < live ? nmodels[(size_t)b * hr + h] : 0;
+        if (exact5 && nm != 1) nm = 0;
+        s_nm[h] = nm;
+    }
+    for (int i = tid; i < live * kMaxModels; i += UPD_T) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
     if (samples_log) {
         const int32_t* src = samples + (size_t)b * samples_stride;
         const int lim = min(live, log_cap - h0);
-        for (int i = lane; i < lim * 5; i += 128) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
+        for (int i = tid; i < lim * 5; i += UPD_T) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
     }
-    if (lane == 0) s_drawn = 0;
+    // The sample stream does not depend on the round's outcome - only how many sets are needed
+    // does, and the iteration bound can only shrink during the replay - so the sets are drawn for
+    // the bound as it stood before the replay; surplus sets are never used, and a pair that ends
+    // in this round never looks at the stream again.
+    const int want = next_round > 0 ? min(next_round, niters0 - (h0 + hr)) : 0;
+    // (fewer than 16 points: most sets hold repeats; more than 65535: the values do not fit 16
+    // bits - both rare in practice - then one lane draws the plain way)
+    const bool fast_draw = want > 0 && n >= 16 && n < 65536;
+    // draws to keep: five per set, a tenth more and a chunk for repeats; whole chunks
+    const int R = min(UPD_RAW, (5 * want + (want >> 1) + 2 * UPD_CHUNK - 1) / UPD_CHUNK * UPD_CHUNK);
+    if (tid == 0) {
+        s_drawn = 0;
+        s_plain = want > 0 && !fast_draw;
+    }
     __syncthreads();
-    // Two serial jobs side by side, one lane of each wavefront: the bookkeeping replay below, and
-    // the next round's samples.  The sample stream does not depend on the round's outcome - only
-    // how many are needed does, and the iteration bound can only shrink during the replay - so
-    // the second wavefront draws for the bound as it stood before the replay; surplus sets are
-    // never used, and a pair that ends in this round never looks at the stream again.
-    if (lane == 64 && next_round > 0) {
-        RState d = stv[b];
-        const int want = min(next_round, d.niters - (h0 + hr));
-        if (want > 0) {
-            draw_samples(d, samples + (size_t)b * samples_stride, want);
-            s_rng = d.rng;
-            s_drawn = 1;
-        }
-    }
-    RState s;
-    int h = 0, best_h = -1, best_k = 0;
-    if (lane == 0) {
-    s = stv[b];
-    for (; h < hr; ++h) {
-        if (h0 + h >= s.niters) break;
-        int nm = s_nm[h];
-        if (s.exact5 && nm != 1) nm = 0;
-        s.models_scored += nm;
+    for (int h = tid; h < UPD_MAX_HR; h += UPD_T) {
+        int best = -1, bk = 0;
+        const int nm = s_nm[h];
         for (int k = 0; k < nm; ++k) {
-            int good = s_cnt[h * kMaxModels + k];
-            if (good > max(s.max_good, 4)) {
+            const int good = s_cnt[h * kMaxModels + k];
+            if (good > best) { best = good; bk = k; }
+        }
+        s_hb[h] = best;
+        s_hk[h] = (uint8_t)bk;
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128 && fast_draw && (tid - 64) * UPD_CHUNK < R) {   // second wavefront: the raw stream, 48 draws per lane
+        const int j = tid - 64;
+        const unsigned long long g0 = stv[b].rng;
+        unsigned long long g = j == 0 ? g0 : mwc_mulmod(g0, d_mwc_jump[j]);
+        if (j > 0 && g < 2) s_plain = 1;   // the residue does not tell the states p, p + 1 from 0, 1 (never seen)
+        s_ck[j] = g;
+#pragma unroll 4
+        for (int i = 0; i < UPD_CHUNK; ++i) s_raw[j * UPD_CHUNK + i] = rng_next(g);
+        if ((j + 1) * UPD_CHUNK == R) s_ck[j + 1] = g;
+    }
+    // the replay, first wavefront: lane L owns hypotheses 8L .. 8L+7
+    RState s;
+    int best_h = -1;
+    if (tid < 64) {
+        int v[8], lane_max = -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = s_hb[8 * tid + j];
+            lane_max = max(lane_max, v[j]);
+        }
+        int incl = lane_max;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int u = __shfl_up(incl, o);
+            if (tid >= o) incl = max(incl, u);
+        }
+        int before = __shfl_up(incl, 1);
+        s = stv[b];
+        int cur = max(max(s.max_good, 4), tid > 0 ? before : -1);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v[j] > cur) {
+                cur = v[j];
+                bits |= 1u << j;
+            }
+        s_imp[tid] = (uint8_t)bits;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the strict improvements in order; between two of them the bound is constant
+        int last = -1;
+        bool ended = false;
+        for (int L = 0; L < 64 && !ended; ++L) {
+            uint32_t bits = s_imp[L];
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int h = 8 * L + j;
+                if (h0 + h >= s.niters) { ended = true; break; }   // the loop ended before it got here
+                const int good = s_hb[h];
                 s.max_good = good;
                 best_h = h;
-                best_k = k;
+                last = h;
                 if (P.fixed_iters <= 0 && !s.exact5)
                     s.niters = update_num_iters(P.confidence, (double)(s.n - good) / s.n, s.niters);
             }
         }
-        s.iters_run = h0 + h + 1;
-    }
-    if (best_h >= 0) {
-        const double* E = models + (((size_t)b * hr + best_h) * kMaxModels + best_k) * 9;
-        for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
-    }
-    if (h < hr || h0 + hr >= s.niters || next_round <= 0) s.done = 1;
+        // the hypothesis of an improvement is completed before the bound is looked at again
+        const int stop = min(hr, max(max(s.niters - h0, 0), last + 1));
+        if (stop > 0) s.iters_run = h0 + stop;
+        if (best_h >= 0) {
+            const double* E = models + (((size_t)b * hr + best_h) * kMaxModels + s_hk[best_h]) * 9;
+            for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
+        }
+        if (stop < hr || h0 + hr >= s.niters || next_round <= 0) s.done = 1;
+        s_stop = stop;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid < 64) {   // candidates of the hypotheses the loop walked
+        const int stop = s_stop;
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (8 * tid + j < stop) sum += s_nm[8 * tid + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (tid == 0) s.models_scored += sum;
+    }
+    int32_t* out = samples + (size_t)b * samples_stride;
+    const bool plain = s_plain != 0;
+    if (want > 0 && plain) {
+        if (tid == 64) {
+            RState d;
+            d.rng = stv[b].rng;
+            d.n = n;
+            draw_samples(d, out, want);
+            s_rng = d.rng;
+            s_drawn = 1;
+        }
+    } else if (want > 0) {   // workgroup-uniform
+        for (int i = tid; i < R; i += UPD_T) s_val[i] = (uint16_t)(s_raw[i] % (uint32_t)n);
+        __syncthreads();
+        for (int i = tid; i < ((R + 63) & ~63); i += UPD_T) {
+            bool distinct = false;
+            if (i + 5 <= R) {
+                const int a0 = s_val[i], a1 = s_val[i + 1], a2 = s_val[i + 2], a3 = s_val[i + 3], a4 = s_val[i + 4];
+                distinct = a0 != a1 && a0 != a2 && a0 != a3 && a0 != a4 && a1 != a2 && a1 != a3 && a1 != a4 && a2 != a3 &&
+                           a2 != a4 && a3 != a4;
+            }
+            const unsigned long long m = __ballot(distinct);
+            if ((tid & 63) == 0) s_w5[i >> 6] = m;
+        }
+        __syncthreads();
+        if (tid == 64) {   // set starts
+            int pos = 0, h = 0, word = -1;
+            unsigned long long bits = 0;
+            for (; h < want; ++h) {
+                if (pos >= R) break;
+                if ((pos >> 6) != word) {
+                    word = pos >> 6;
+                    bits = s_w5[word];
+                }
+                int nxt;
+                if ((bits >> (pos & 63)) & 1ull) nxt = pos + 5;
+                else {
+                    int idx[5];
+                    nxt = take_set(s_val, pos, R, idx);
+                    if (nxt < 0) break;   // the kept draws run out inside this set
+                }
+                s_off[h] = (uint16_t)pos;
+                pos = nxt;
+            }
+            s_sets = h;
+            s_end = pos;
+        }
+        __syncthreads();
+        const int sets = s_sets;
+        for (int h = tid; h < sets; h += UPD_T) {
+            const int pos = s_off[h];
+            int idx[5];
+            if ((s_w5[pos >> 6] >> (pos & 63)) & 1ull) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) idx[i] = s_val[pos + i];
+            } else {
+                take_set(s_val, pos, R, idx);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) out[h * 5 + i] = idx[i];
+        }
+        if (tid == 64) {
+            const int at = s_end;   // draws consumed by the complete sets
+            unsigned long long g = s_ck[at / UPD_CHUNK];
+            for (int i = 0; i < at % UPD_CHUNK; ++i) rng_next(g);
+            if (sets < want) {   // more repeats than the kept draws cover: the rest the plain way
+                RState d;
+                d.rng = g;
+                d.n = n;
+                draw_samples(d, out + sets * 5, want - sets);
+                g = d.rng;
+            }
+            s_rng = g;
+            s_drawn = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
         if (s_drawn) s.rng = s_rng;
         stv[b] = s;
     }
@@ -1879,6 +2078,20 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if ((rc = ensure(c, c->r_nroots, (size_t)batch * HR * 4))) return rc;
     if ((rc = ensure(c, c->r_best, (size_t)batch * HR * HYP_REC * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
+    {
+        static std::mutex jump_mutex;
+        static bool jump_loaded[64] = {};
+        std::lock_guard<std::mutex> lk(jump_mutex);
+        if (!jump_loaded[c->device]) {
+            unsigned long long t[64], g = 1;
+            for (int j = 0; j < 64; ++j) {
+                t[j] = g;
+                for (int k = 0; k < UPD_CHUNK; ++k) g = (unsigned long long)(uint32_t)g * kMwcA + (uint32_t)(g >> 32);
+            }
+            VO_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(d_mwc_jump), t, sizeof(t)));
+            jump_loaded[c->device] = true;
+        }
+    }
     RState* st = (RState*)c->r_state.p;
     double* m = (double*)c->r_pts.p;
     int32_t* samples = (int32_t*)c->r_samples.p;
@@ -1933,7 +2146,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         t_end_on(c, VO_T_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(128), 0, s, st, batch, P, h0, hr, models, nmodels,
+        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, models, nmodels,
                            counts, samples, HR * 5, next, d_samples, samples_cap, retry_list);
         h0 += hr;
     }
