@@ -400,6 +400,34 @@ def test_five_point_models_match_oracle(ctx, oracle):
     assert same >= 0.95 * n_sets
 
 
+def test_five_point_with_a_repeated_point(ctx, oracle):
+    # Two equal correspondences in a sample (keypoints of two pyramid levels at one position do
+    # that in practice) leave four constraints: the degree-10 polynomial loses its leading
+    # coefficient and the solutions form a family.  Whatever comes out must still be a solution,
+    # and the call must not stall on such sets (they take the same parallel path as the others).
+    rng = np.random.default_rng(78)
+    n_sets, same = 128, 0
+    x1 = rng.uniform(-0.6, 0.6, (n_sets, 5, 2))
+    R = np.array([[0.9998, -0.0175, 0.01], [0.0176, 0.9998, -0.005], [-0.0099, 0.0052, 0.99994]])
+    Z = rng.uniform(3, 12, (n_sets, 5, 1))
+    X = np.concatenate([x1 * Z, Z], 2)
+    Y = X @ R.T + np.array([0.3, -0.05, 0.1])
+    x2 = Y[..., :2] / Y[..., 2:] + rng.normal(0, 1e-3, (n_sets, 5, 2))
+    x1[:, 4], x2[:, 4] = x1[:, 1], x2[:, 1]
+    got = ctx.five_point(x1, x2)
+    n_models = 0
+    for i in range(n_sets):
+        ref = oracle.five_point(x1[i], x2[i])
+        n_models += len(got[i])
+        for E in got[i]:
+            r = [np.array([*x2[i, k], 1]) @ E @ np.array([*x1[i, k], 1]) for k in range(5)]
+            assert np.max(np.abs(r)) < 1e-9 and abs(np.linalg.det(E)) < 1e-9
+        if len(ref) == len(got[i]) and all(
+                min(min(np.abs(E - F).max(), np.abs(E + F).max()) for F in ref) < 1e-8 for E in got[i]):
+            same += 1
+    print("repeated-point sets: GPU models", n_models, "sets equal to the oracle's", same, "of", n_sets)
+
+
 def test_motion_validity_rules(ctx):
     # ref:src/motion_estimator.cpp:52-54,83-85
     p1 = np.array([[100, 100], [200, 200], [300, 300]], np.float32)

@@ -801,7 +801,7 @@ struct RootsShared {             // the nine derivative levels
                                  // 4 right end is a touching extremum
     uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
     int16_t np[HB];              // roots in the current list
-    uint8_t levels[HB];          // 1: the hypothesis runs the nine levels
+    uint8_t deg[HB];             // degree of the hypothesis' polynomial (0: nothing to solve)
     int total;
 };
 constexpr int HBM = 96;           // hypotheses per workgroup of the model stage on its own: 4.4 candidates each on
@@ -871,23 +871,30 @@ __device__ __forceinline__ void number_items_wide(SH& sh) {
 template <int DEG>
 __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
     const int tid = threadIdx.x;
-    if (tid < 64) number_items(sh, tid, sh.levels[tid] ? sh.np[tid] + 1 : 0);
+    constexpr int J = 10 - DEG;
+    // A polynomial of degree n < 10 (its upper coefficients are stored as zeros) joins at the
+    // level where its J-th derivative is linear - one unbounded piece, no list yet - and from
+    // there on is a polynomial of degree e = n - J inside the arrays of degree DEG.
+    if (tid < 64) number_items(sh, tid, (int)sh.deg[tid] - J >= 1 ? sh.np[tid] + 1 : 0);
     __syncthreads();
     const int total = sh.total;
     for (int item = tid; item < total; item += BACK_THREADS) {
         const int h = sh.map[item] & 0xFF, g = sh.map[item] >> 8;
         const int np = sh.np[h];
-        constexpr int J = 10 - DEG;
+        const int e = (int)sh.deg[h] - J;   // 1 .. DEG
         double d[DEG + 1], dd[DEG];
 #pragma unroll
         for (int i = 0; i <= DEG; ++i) d[i] = sh.cf[h][i + J] * falling(i + J, J);
 #pragma unroll
         for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
         // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
-        double R = 0;
+        double R = 0, lead = d[DEG];
 #pragma unroll
-        for (int i = 0; i < DEG; ++i) R = fmax(R, fabs(d[i]));
-        R = R / fabs(d[DEG]) * (1.0 + 1e-12) + 1.0;
+        for (int i = 0; i < DEG; ++i) {
+            if (i < e) R = fmax(R, fabs(d[i]));
+            if (i == e) lead = d[i];
+        }
+        R = R / fabs(lead) * (1.0 + 1e-12) + 1.0;
         if (g == 0) sh.bound[h] = R;
         const double* sP = sh.list[h][si];
         // Inner pieces lie between two roots of the derivative.  The two outer pieces are
@@ -906,7 +913,7 @@ __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
             fb = horner<DEG>(d, b);
         }
         const double bT = right_open ? 0.0 : b, fbT = right_open ? 0.0 : fb;   // inner right end, for the extremum test
-        const bool lead_neg = d[DEG] < 0;
+        const bool lead_neg = lead < 0;
         bool at_pivot = false;   // monotone polynomial with a zero exactly at the pivot
         if (left_open || right_open) {
             double p, fp, dir;
@@ -921,7 +928,7 @@ __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
                 p = b; fp = fb; dir = -1.0;
             }
             // sign of the polynomial at dir * infinity
-            const bool inf_neg = dir > 0 ? lead_neg : (lead_neg != ((DEG & 1) != 0));
+            const bool inf_neg = dir > 0 ? lead_neg : (lead_neg != ((e & 1) != 0));
             double q = p, fq = fp;
             if (fp != 0.0 && ((fp < 0) != inf_neg)) {
                 double step = 1e-3 * fmax(1.0, fabs(p));
@@ -991,7 +998,7 @@ __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
     }
     __syncthreads();
     // the ordered bookkeeping of the one-lane routine, one lane per hypothesis
-    if (tid < HB && sh.levels[tid]) {
+    if (tid < HB && (int)sh.deg[tid] - J >= 1) {
         const int h = tid, np = sh.np[h];
         const double R = sh.bound[h];
         const double* sP = sh.list[h][si];
@@ -1064,28 +1071,34 @@ __device__ __forceinline__ void roots_block(RootsShared& sh, int count, const do
     if (tid < HB) {
         const int h = tid;
         const double* rec = rec0 + (size_t)h * HYP_REC;
-        int np = 0;
-        bool run = false;
+        int np = 0, n = 0;
         if (h < count && rec[0] != 0.0) {
             double cf[11], cmax = 0;
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
                 cf[i] = rec[1 + i];
-                sh.cf[h][i] = cf[i];
                 cmax = fmax(cmax, fabs(cf[i]));
             }
-            if (fabs(cf[10]) > 1e-14 * cmax) {
-                sh.list[h][0][0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
-                np = 1;
-                run = true;
-            } else {   // degree-deficient polynomial (rare): generic one-lane path
-                double roots[10];
-                np = real_roots(cf, roots);
-                for (int k = 0; k < np; ++k) sh.list[h][1][k] = roots[k];
+            if (cmax > 0 && cmax < DBL_MAX) {
+                // degree: upper coefficients that vanish against the largest one do not count (a
+                // degenerate sample can make the leading one exactly zero).  Such a polynomial goes
+                // through the same levels as the others: a single lane solving it the generic way
+                // takes 200 us and holds its whole workgroup - and, in a round that fills the GPU
+                // once, the round.
+                n = 10;
+#pragma unroll
+                for (int i = 10; i >= 1; --i)
+                    if (n == i && fabs(cf[i]) <= 1e-14 * cmax) n = i - 1;
+#pragma unroll
+                for (int i = 0; i < 11; ++i) sh.cf[h][i] = i <= n ? cf[i] : 0.0;
+                if (n == 10) {
+                    sh.list[h][0][0] = -(cf[9] * falling(9, 9)) / (cf[10] * falling(10, 9));   // root of the 9th derivative
+                    np = 1;
+                }
             }
         }
         sh.np[h] = (int16_t)np;
-        sh.levels[h] = run ? 1 : 0;
+        sh.deg[h] = (uint8_t)n;
     }
     __syncthreads();
     roots_level_block<2>(sh, 0);
