@@ -38,7 +38,7 @@ PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": 
 KERNEL_OF_GROUP = {
     "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel", "select": "select_a + harris + select_b kernels",
     "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_bcast_kernel",
-    "ratio": "ratio_kernel", "ransac_solve": "solve_front_kernel + solve_back_kernel", "ransac_score": "score_kernel",
+    "ratio": "ratio_kernel", "ransac_solve": "solve_front_kernel + solve_roots_kernel + solve_models_kernel (+ second-chart pass)", "ransac_score": "score_kernel",
     "ransac_other": "normalize / init / update / finish kernels",
 }
 BOUND_OF_GROUP = {"resize": "hbm", "fast": "hbm", "select": "hbm", "blur": "hbm", "describe": "hbm", "knn2": "valu_int",
