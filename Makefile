@@ -18,7 +18,7 @@ visual_odometry_amd/libvo_hip.so: $(OBJS)
 # C++20 drop-in layer (the reference's interfaces over the C ABI, plus the callers either side
 # of the path: image loader, trajectory, batched sequence helper) and its test binaries
 CXX ?= g++
-HOST_SRCS := $(CSRC)/host/vo_cpp_api.cpp $(CSRC)/host/vo_trajectory.cpp $(CSRC)/host/vo_image_loader.cpp $(CSRC)/host/vo_draw.cpp
+HOST_SRCS := $(CSRC)/host/vo_cpp_api.cpp $(CSRC)/host/vo_trajectory.cpp $(CSRC)/host/vo_image_loader.cpp $(CSRC)/host/vo_jpeg.cpp $(CSRC)/host/vo_draw.cpp
 visual_odometry_amd/libvisual_odometry_hip.so: $(HOST_SRCS) include/visual_odometry/*.hpp include/visual_odometry/compat/*.hpp include/vo_hip.h visual_odometry_amd/libvo_hip.so
 	$(CXX) -std=c++20 -O2 -fPIC -shared -Iinclude -o $@ $(HOST_SRCS) -Lvisual_odometry_amd -lvo_hip -lz -Wl,-rpath,'$$ORIGIN'
 

@@ -95,8 +95,35 @@ def dataset(tmp_path_factory):
     pgm = rng.integers(0, 256, (8, 12), dtype=np.uint8)
     (d / "08_pgm.png").write_bytes(b"P5\n# comment\n12 8\n255\n" + pgm.tobytes())
     expect["08_pgm.png"] = pgm
-    Image.fromarray(rgb).save(d / "09_photo.jpg", quality=90)
-    expect["09_photo.jpg"] = None          # JPEG: "Failed to load image"
+    # JPEG: the luma plane as libjpeg delivers it (Pillow's draft mode "L" asks libjpeg-turbo for
+    # grayscale output, which is what cv::imread(IMREAD_GRAYSCALE) does)
+    def jpeg_luma(path):
+        im = Image.open(path)
+        im.draft("L", im.size)
+        im.load()
+        assert im.mode == "L"
+        return np.asarray(im).copy()
+    yy, xx = np.mgrid[0:217, 0:333]
+    photo = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 7) % 256], -1).astype(np.uint8)
+    photo[40:120, 60:200] = rng.integers(0, 256, (80, 140, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(d / "09_photo.jpg", quality=90)                        # 41 x 19, 4:2:0
+    Image.fromarray(photo).save(d / "09a_420.jpg", quality=85)                        # odd size, 4:2:0
+    Image.fromarray(photo).save(d / "09b_444.jpeg", quality=95, subsampling=0)
+    Image.fromarray(photo).save(d / "09c_422.jpg", quality=60, subsampling=1)
+    Image.fromarray(photo[..., 0]).save(d / "09d_gray.jpg", quality=75)
+    Image.fromarray(photo).save(d / "09e_optimized.jpg", quality=80, optimize=True)   # file-specific Huffman tables
+    try:
+        Image.fromarray(photo).save(d / "09f_restart.jpg", quality=80, restart_marker_blocks=7)
+    except TypeError:
+        Image.fromarray(photo).save(d / "09f_restart.jpg", quality=80)
+    for name in ("09_photo.jpg", "09a_420.jpg", "09b_444.jpeg", "09c_422.jpg", "09d_gray.jpg", "09e_optimized.jpg",
+                 "09f_restart.jpg"):
+        expect[name] = jpeg_luma(d / name)
+    Image.fromarray(photo).save(d / "09g_progressive.jpg", quality=80, progressive=True)
+    expect["09g_progressive.jpg"] = None   # progressive files are refused: "Failed to load image"
+    whole = (d / "09a_420.jpg").read_bytes()
+    (d / "09h_truncated.jpg").write_bytes(whole[: len(whole) // 2])
+    expect["09h_truncated.jpg"] = None     # a file that ends inside the entropy-coded data is refused
     (d / "10_broken.png").write_bytes(b"\x89PNG\r\n\x1a\nnot really")
     expect["10_broken.png"] = None
     # a 65-byte file whose header promises 32768 x 32768 RGBA16 pixels (8.6 GB): refused before any allocation
@@ -133,8 +160,8 @@ def test_trajectory_and_loader(dataset):
     assert stamps["00_gray8.png"] == pytest.approx(1305031102.1753, abs=1e-3)
     assert stamps["01_rgb.png"] == pytest.approx(1305031102.2112, abs=1e-3)
     assert stamps["02_gray16.png"] == 0.0
-    # the pair walk stops at the first undecodable file (index 9)
-    assert lines[-2] == "pairs 8"
+    # the pair walk stops at the first undecodable file (the progressive JPEG, index 16)
+    assert lines[-2] == "pairs 15"
 
 
 def test_python_api_host_side(dataset, tmp_path):

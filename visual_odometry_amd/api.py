@@ -236,12 +236,23 @@ class TimestampedImagePair:
 
 
 def read_gray_image(path):
-    """8-bit grayscale of a PNG/PGM/PPM file, reduced like the C++ loader (high byte of 16-bit
-    samples, BT.601 fixed-point weights for colour); None if it cannot be decoded.  JPEG is refused
-    as in the C++ loader."""
+    """8-bit grayscale of a PNG/PGM/PPM/JPEG file, reduced like the C++ loader (high byte of 16-bit
+    samples, BT.601 fixed-point weights for colour; of a sequential JPEG the luma plane as libjpeg
+    decodes it, progressive and CMYK files refused); None if it cannot be decoded."""
     try:
         from PIL import Image
         with Image.open(path) as im:
+            if im.format == "JPEG":
+                if im.info.get("progressive") or im.mode not in ("L", "RGB"):
+                    return None
+                im.draft("L", im.size)
+                import warnings
+                from PIL import ImageFile
+                assert not ImageFile.LOAD_TRUNCATED_IMAGES
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")
+                    im.load()   # a truncated file raises (refused, as in the C++ loader)
+                return np.asarray(im).copy() if im.mode == "L" else None
             if im.format not in ("PNG", "PPM"):
                 return None
             if im.mode in ("I;16", "I;16B", "I"):

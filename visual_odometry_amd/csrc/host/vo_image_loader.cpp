@@ -1,6 +1,6 @@
 // Directory image source and grayscale decoders (interface: include/visual_odometry/image_loader.hpp;
 // behaviour of ref:src/image_loader.cpp:31-216 with cv::imread(..., IMREAD_GRAYSCALE) replaced by
-// a zlib-based PNG reader and a PGM/PPM reader).
+// a zlib-based PNG reader, a PGM/PPM reader and the sequential-JPEG luma decoder of vo_jpeg.cpp).
 #include <algorithm>
 #include <cctype>
 #include <cstdint>
@@ -15,6 +15,10 @@
 #include <visual_odometry/image_loader.hpp>
 
 namespace visual_odometry {
+
+namespace detail {
+auto decode_jpeg_gray(std::vector<uint8_t> const& file) -> cv::Mat;   // vo_jpeg.cpp
+}
 
 namespace {
 
@@ -241,7 +245,8 @@ auto read_gray_image(std::string const& path) -> cv::Mat {
     std::vector<uint8_t> file;
     if (!read_file(path, file)) return {};
     if (file.size() >= 2 && file[0] == 'P') return decode_pnm(file);
-    return decode_png(file);   // anything else (JPEG included) comes back empty
+    if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8) return detail::decode_jpeg_gray(file);
+    return decode_png(file);   // anything else comes back empty
 }
 
 image_loader::image_loader(std::string image_directory, std::vector<std::string> image_paths, std::vector<double> timestamps)
