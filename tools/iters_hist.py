@@ -8,7 +8,7 @@ from visual_odometry_amd import capi, synth
 P = 128
 frames = []
 for p in range(P):
-    frames += list(synth.frame_pair(0x5EED0000 + p, sparse=True, moving_fraction=0.6, n_layers=24))
+    frames += list(synth.frame_pair(0x5EED0000 + p, sparse=True, moving_fraction=0.6, n_layers=24) if "--dense" not in sys.argv else synth.frame_pair(0x5EED0000 + p))
 imgs = torch.from_numpy(np.stack(frames)).cuda()
 ctx = capi.Context(0)
 res = torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
