@@ -362,11 +362,16 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             // pixels that passed in both polarities (saddle-like neighbourhoods, about one in a
             // hundred entries): a second entry for the brighter-ring polarity
             const uint32_t both = TD & TB;
-            if (__ballot(both != 0)) {
-                wave_push(both & 0x80u, (uint16_t)pos, q1, &n1, lane);
-                wave_push(both & 0x8000u, (uint16_t)(pos + 1), q1, &n1, lane);
-                wave_push(both & 0x800000u, (uint16_t)(pos + 2), q1, &n1, lane);
-                wave_push(both & 0x80000000u, (uint16_t)(pos + 3), q1, &n1, lane);
+            if (__ballot(both != 0)) {   // (some lane of three wavefront passes in four on the dense scene)
+                // the one or two lanes concerned append for themselves: a per-lane LDS add, where
+                // four more ballot-and-compact rounds cost five times the instructions
+                if (both) {
+                    uint32_t s = lds_fetch_add(&n1, (uint32_t)__popc(both));
+                    if (both & 0x80u) q1[s++] = (uint16_t)pos;
+                    if (both & 0x8000u) q1[s++] = (uint16_t)(pos + 1);
+                    if (both & 0x800000u) q1[s++] = (uint16_t)(pos + 2);
+                    if (both & 0x80000000u) q1[s] = (uint16_t)(pos + 3);
+                }
             }
         }
     }
