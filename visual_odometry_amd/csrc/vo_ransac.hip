@@ -1394,20 +1394,44 @@ __device__ __forceinline__ bool sampson_inlier_dev(const double* E, double x1, d
     return (float)(num / den) <= t2;
 }
 
-// One wavefront per hypothesis: every lane walks the points with stride 64,
-// evaluates all of the hypothesis' models on each, and the per-lane inlier
-// counts are summed across the wave.
+// One wavefront per hypothesis: every lane walks the points with stride 64, evaluates all of
+// the hypothesis' models on each, and the per-lane inlier counts are summed across the wave.
+//
+// The decision must be the double-precision one (sampson_inlier_dev), but nearly every point
+// is far from the threshold, and far from it single precision decides as well: the models go
+// through packed single-precision fused multiply-adds two at a time (a fifth of the
+// instructions of the double path, whose products and sums stay separate to match the CPU),
+// with a bound on what rounding can have done to num - t2 * den; a test whose result is inside
+// the bound goes on a per-wavefront list (one in a hundred on small-baseline pairs, where every
+// near-skew model puts all points within a few pixels of their epipolar lines) and the lists are
+// worked off in double precision by full wavefronts.
+// The bound, with u = 2^-24, unit-norm E (|e_i| <= 1), M1 = 1 + |x1| + |y1|, M2 likewise:
+// inputs and each fused step round by u, so the rows of E x1 are off by < 6 u M1, the epipolar
+// product d by < 10 u M1 M2 (dd below takes 24 u M1 M2), num = d^2 by < 2 |d| dd + 3 dd^2 + u num,
+// den by < 34 u max(M1, M2) sqrt(den) + 4 u den, which with t2 in front is below
+// t2 (9 u M^2 + 36 u den); the sum is under  4 dd |d| + 64 u (num + t2 den) + 4 dd^2 + 16 u t2 (M1^2 + M2^2).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ st, const double* __restrict__ m,
                                                     int n_max, int hr, const double* __restrict__ models,
                                                     const int32_t* __restrict__ nmodels, float t2, double t2_mid,
                                                     int32_t* __restrict__ counts) {
+    constexpr int QCAP = 512;   // undecided tests kept per wavefront; an iteration adds at most 128
     __shared__ double sE[4][kMaxModels * 9];
+    __shared__ __attribute__((aligned(8))) float sEf[4][kMaxModels / 2][9][2];   // element i of models 2p and 2p + 1
+    __shared__ uint32_t s_q[4][QCAP];        // model << 24 | point
+    __shared__ int s_extra[4][kMaxModels];   // inliers found among the listed tests
     int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (st[b].done) return;   // workgroup-uniform: the solve kernel wrote nothing for this pair
     int h = blockIdx.x * 4 + wave;
     int nm = h < hr ? nmodels[(size_t)b * hr + h] : 0;   // wave-uniform
     const double* Eg = models + ((size_t)b * hr + h) * kMaxModels * 9;
-    for (int i = lane; i < nm * 9; i += 64) sE[wave][i] = Eg[i];
+    for (int i = lane; i < kMaxModels * 9; i += 64) {
+        const double e = i < nm * 9 ? Eg[i] : 0.0;
+        const int k = i / 9, q = i - k * 9;
+        sE[wave][i] = e;
+        sEf[wave][k >> 1][q][k & 1] = (float)e;
+    }
+    if (lane < kMaxModels) s_extra[wave][lane] = 0;
     __syncthreads();
     if (nm == 0) return;
     int n = st[b].n;
@@ -1415,19 +1439,76 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
 #pragma unroll
     for (int k = 0; k < kMaxModels; ++k) cnt[k] = 0;
     const double* pb = m + (size_t)b * n_max * 4;
-    for (int i = lane; i < n; i += 64) {
-        const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)i * 4);
+    constexpr float U = 5.9604645e-8f;   // 2^-24
+    const float t2m = (float)t2_mid;
+    const f32x2 T2M = {t2m, t2m};
+    uint32_t* q = s_q[wave];
+    int qn = 0;   // wave-uniform
+    auto flush = [&]() {
+        for (int base = 0; base < qn; base += 64) {
+            const int idx = base + lane;
+            if (idx < qn) {
+                const uint32_t ent = q[idx];
+                const int k = (int)(ent >> 24);
+                const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)(ent & 0xFFFFFFu) * 4);
+                if (sampson_inlier_dev(&sE[wave][k * 9], p.x, p.y, p.z, p.w, t2, t2_mid)) atomicAdd(&s_extra[wave][k], 1);
+            }
+        }
+        qn = 0;
+    };
+    auto defer = [&](bool und, uint32_t ent) {   // appends the undecided lanes' entries in lane order
+        const unsigned long long mk = __ballot(und);
+        if (mk == 0) return;
+        if (und) q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = ent;
+        qn += (int)__popcll(mk);
+    };
+    static_assert(kMaxModels <= 128 && QCAP >= 2 * 128, "list entry layout and room for one iteration");
+    for (int i0 = 0; i0 < n; i0 += 64) {   // (all lanes stay in the loop: the list is a wavefront's)
+        const int i = i0 + lane;
+        const bool live = i < n;
+        const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)(live ? i : 0) * 4);
+        const float x1 = (float)p.x, y1 = (float)p.y, x2 = (float)p.z, y2 = (float)p.w;
+        const float m1 = 1.0f + fabsf(x1) + fabsf(y1), m2 = 1.0f + fabsf(x2) + fabsf(y2);
+        const float dd = 24.0f * U * m1 * m2;
+        const float c0 = 4.0f * dd * dd + 16.0f * U * t2m * (m1 * m1 + m2 * m2);
+        const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, X2 = {x2, x2}, Y2 = {y2, y2};
+        const f32x2 DD4 = {4.0f * dd, 4.0f * dd}, C0 = {c0, c0}, U64 = {64.0f * U, 64.0f * U};
 #pragma unroll
-        for (int k = 0; k < kMaxModels; ++k)
-            if (k < nm) cnt[k] += sampson_inlier_dev(&sE[wave][k * 9], p.x, p.y, p.z, p.w, t2, t2_mid);
+        for (int pr = 0; pr < kMaxModels / 2; ++pr) {
+            if (2 * pr >= nm) break;   // wave-uniform
+            if (qn > QCAP - 128) flush();
+            const f32x2* e = reinterpret_cast<const f32x2*>(&sEf[wave][pr][0][0]);
+            const f32x2 a0 = __builtin_elementwise_fma(e[0], X1, __builtin_elementwise_fma(e[1], Y1, e[2]));
+            const f32x2 a1 = __builtin_elementwise_fma(e[3], X1, __builtin_elementwise_fma(e[4], Y1, e[5]));
+            const f32x2 a2 = __builtin_elementwise_fma(e[6], X1, __builtin_elementwise_fma(e[7], Y1, e[8]));
+            const f32x2 b0 = __builtin_elementwise_fma(e[0], X2, __builtin_elementwise_fma(e[3], Y2, e[6]));
+            const f32x2 b1 = __builtin_elementwise_fma(e[1], X2, __builtin_elementwise_fma(e[4], Y2, e[7]));
+            const f32x2 d = __builtin_elementwise_fma(X2, a0, __builtin_elementwise_fma(Y2, a1, a2));
+            const f32x2 num = d * d;
+            const f32x2 den = __builtin_elementwise_fma(
+                a0, a0, __builtin_elementwise_fma(a1, a1, __builtin_elementwise_fma(b0, b0, b1 * b1)));
+            const f32x2 r = __builtin_elementwise_fma(-T2M, den, num);
+            const f32x2 bound = __builtin_elementwise_fma(
+                __builtin_elementwise_abs(d), DD4, __builtin_elementwise_fma(U64, __builtin_elementwise_fma(T2M, den, num), C0));
+            // (written so that a NaN anywhere counts as undecided)
+            const bool second = 2 * pr + 1 < nm;
+            const bool und0 = live && !(fabsf(r.x) > bound.x), und1 = live && second && !(fabsf(r.y) > bound.y);
+            cnt[2 * pr] += live && !und0 && r.x < 0.0f;
+            cnt[2 * pr + 1] += live && second && !und1 && r.y < 0.0f;
+            if (__any(und0 | und1)) {
+                defer(und0, ((uint32_t)(2 * pr) << 24) | (uint32_t)i);
+                defer(und1, ((uint32_t)(2 * pr + 1) << 24) | (uint32_t)i);
+            }
+        }
     }
+    flush();
 #pragma unroll
     for (int k = 0; k < kMaxModels; ++k) {
         if (k >= nm) break;
         int v = cnt[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) counts[((size_t)b * hr + h) * kMaxModels + k] = v;
+        if (lane == 0) counts[((size_t)b * hr + h) * kMaxModels + k] = v + s_extra[wave][k];
     }
 }
 
