@@ -132,7 +132,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
                       &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->img_status, &c->fast_stats, &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->st_down,  &c->m_top2,   &c->m_qidx,
                       &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
-                      &c->r_models, &c->r_nmodels, &c->r_models2, &c->r_nmodels2, &c->r_retry, &c->r_roots, &c->r_nroots, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_res,
+                      &c->r_models, &c->r_nmodels, &c->r_models2, &c->r_nmodels2, &c->r_retry, &c->r_roots, &c->r_nroots, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_ptsf, &c->r_res,
                       &c->p_kps,    &c->p_desc,   &c->p_cnt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);

@@ -103,7 +103,7 @@ struct vo_ctx {
     size_t h_pin_bytes = 0;
     // matching / RANSAC workspace
     vo::DevBuf m_top2, m_qidx, m_tidx, m_dist, m_p1, m_p2, m_cnt;
-    vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_roots, r_nroots, r_counts, r_best, r_mask, r_pts, r_res;
+    vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_roots, r_nroots, r_counts, r_best, r_mask, r_pts, r_ptsf, r_res;
     // pipeline workspace
     vo::DevBuf p_kps, p_desc, p_cnt;
 };

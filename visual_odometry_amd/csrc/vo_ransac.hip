@@ -47,7 +47,8 @@ struct RParams {
 
 // ------------------------------------------------------------------ points
 __global__ void normalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
-                                 const int32_t* __restrict__ n_arr, int n_max, RParams P, double* __restrict__ m) {
+                                 const int32_t* __restrict__ n_arr, int n_max, RParams P, double* __restrict__ m,
+                                 float* __restrict__ mf) {
     int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     int n = n_arr ? min(n_arr[b], n_max) : n_max;
     if (i >= n) return;
@@ -56,6 +57,8 @@ __global__ void normalize_kernel(const float* __restrict__ p1, const float* __re
     double x2 = (double)p2[o * 2] * P.ifx + P.bx, y2 = (double)p2[o * 2 + 1] * P.ify + P.by;
     double* d = m + o * 4;
     d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
+    // single-precision copy for the scoring kernel's first look at a point (half the bytes)
+    *reinterpret_cast<float4*>(mf + o * 4) = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
 }
 
 __device__ __forceinline__ uint32_t rng_next(unsigned long long& s) {
@@ -1412,7 +1415,8 @@ __device__ __forceinline__ bool sampson_inlier_dev(const double* E, double x1, d
 // t2 (9 u M^2 + 36 u den); the sum is under  4 dd |d| + 64 u (num + t2 den) + 4 dd^2 + 16 u t2 (M1^2 + M2^2).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ st, const double* __restrict__ m,
-                                                    int n_max, int hr, const double* __restrict__ models,
+                                                    const float* __restrict__ mf, int n_max, int hr,
+                                                    const double* __restrict__ models,
                                                     const int32_t* __restrict__ nmodels, float t2, double t2_mid,
                                                     int32_t* __restrict__ counts) {
     constexpr int QCAP = 512;   // undecided tests kept per wavefront; an iteration adds at most 128
@@ -1439,6 +1443,7 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
 #pragma unroll
     for (int k = 0; k < kMaxModels; ++k) cnt[k] = 0;
     const double* pb = m + (size_t)b * n_max * 4;
+    const float* pf = mf + (size_t)b * n_max * 4;
     constexpr float U = 5.9604645e-8f;   // 2^-24
     const float t2m = (float)t2_mid;
     const f32x2 T2M = {t2m, t2m};
@@ -1466,8 +1471,8 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     for (int i0 = 0; i0 < n; i0 += 64) {   // (all lanes stay in the loop: the list is a wavefront's)
         const int i = i0 + lane;
         const bool live = i < n;
-        const double4 p = *reinterpret_cast<const double4*>(pb + (size_t)(live ? i : 0) * 4);
-        const float x1 = (float)p.x, y1 = (float)p.y, x2 = (float)p.z, y2 = (float)p.w;
+        const float4 p = *reinterpret_cast<const float4*>(pf + (size_t)(live ? i : 0) * 4);
+        const float x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
         const float m1 = 1.0f + fabsf(x1) + fabsf(y1), m2 = 1.0f + fabsf(x2) + fabsf(y2);
         const float dd = 24.0f * U * m1 * m2;
         const float c0 = 4.0f * dd * dd + 16.0f * U * t2m * (m1 * m1 + m2 * m2);
@@ -2169,6 +2174,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int nm = std::max(n_max, 1);
     if ((rc = ensure(c, c->r_state, (size_t)batch * sizeof(RState)))) return rc;
     if ((rc = ensure(c, c->r_pts, (size_t)batch * nm * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->r_ptsf, (size_t)batch * nm * 4 * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->r_samples, (size_t)batch * HR * 5 * 4))) return rc;
     if ((rc = ensure(c, c->r_models, (size_t)batch * HR * kMaxModels * 9 * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_nmodels, (size_t)batch * HR * 4))) return rc;
@@ -2195,6 +2201,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     }
     RState* st = (RState*)c->r_state.p;
     double* m = (double*)c->r_pts.p;
+    float* mf = (float*)c->r_ptsf.p;
     int32_t* samples = (int32_t*)c->r_samples.p;
     double* models = (double*)c->r_models.p;
     int32_t* nmodels = (int32_t*)c->r_nmodels.p;
@@ -2209,7 +2216,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     t_begin_on(c, VO_T_RANSAC, s);
     if (n_max > 0)
         hipLaunchKernelGGL(normalize_kernel, dim3((n_max + 255) / 256, batch), dim3(256), 0, s, d_p1, d_p2, d_n, n_max, P,
-                           m);
+                           m, mf);
     int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
     int r0 = std::min(round_size(0, fixed_iters), total);
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
@@ -2244,7 +2251,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         }
         t_end_on(c, VO_T_RANSAC_SOLVE, s);
         t_begin_on(c, VO_T_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, nm, hr, models, nmodels, P.t2, P.t2_mid,
+        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, (const float*)mf, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         t_end_on(c, VO_T_RANSAC_SCORE, s);
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, models, nmodels,
