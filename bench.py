@@ -33,8 +33,10 @@ WORKLOADS = {
 }
 # Ceilings (MI355X): HBM3E spec peak; vector ALUs: 256 CUs x 4 SIMDs x 32 lanes per clock at
 # 2.4 GHz = 7.86e13 lane-operations/s for 32-bit integer work, one fp64 FMA (2 flops) per lane
-# every other clock = 78.6 TFLOP/s.
-PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": (78.6, "TFLOP/s")}
+# every other clock = 78.6 TFLOP/s, one packed fp32 FMA (two lanes' worth: 4 flops) per lane every
+# other clock = 157.3 TFLOP/s.
+PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": (78.6, "TFLOP/s"),
+        "valu_fp32": (157.3, "TFLOP/s")}
 KERNEL_OF_GROUP = {
     "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel", "select": "select_a + harris + select_b kernels",
     "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_bcast_kernel",
@@ -42,8 +44,8 @@ KERNEL_OF_GROUP = {
     "ransac_other": "normalize / init / update / finish kernels",
 }
 BOUND_OF_GROUP = {"resize": "hbm", "fast": "hbm", "select": "hbm", "blur": "hbm", "describe": "hbm", "knn2": "valu_int",
-                  "ratio": "hbm", "ransac_solve": "valu_fp64", "ransac_score": "valu_fp64", "ransac_other": "valu_fp64"}
-SAMPSON_FLOPS = 45.0          # fp64 operations of one (essential matrix, match) Sampson test
+                  "ratio": "hbm", "ransac_solve": "valu_fp64", "ransac_score": "valu_fp32", "ransac_other": "valu_fp64"}
+SAMPSON_FLOPS = 45.0          # operations of one (essential matrix, match) Sampson test (packed fp32 first, fp64 when close)
 FIVE_POINT_FLOPS = 3.0e4      # one five-point solve: null space, 10x20 elimination, degree-10 roots, polishing (estimate)
 KNN_LANE_OPS = 20.0           # per (query, train row): 8 xor + 8 popcount-accumulate + 4 for the top-2 update
 
@@ -277,7 +279,7 @@ def roofline_of(group, work_per_step, avg_ms, launches, steps, workload, P):
     scale = 1e9 if bound == "hbm" else 1e12
     achieved = per_launch / max(avg_ms * 1e-3, 1e-12) / scale
     what = {"hbm": "algorithmic_bytes_per_launch", "valu_int": "algorithmic_lane_ops_per_launch",
-            "valu_fp64": "algorithmic_flops_per_launch"}[bound]
+            "valu_fp64": "algorithmic_flops_per_launch", "valu_fp32": "algorithmic_flops_per_launch"}[bound]
     return {"bound": bound, "kernel": KERNEL_OF_GROUP[group], "achieved": achieved, "peak": peak, "unit": unit,
             "frac": achieved / peak, "traffic": measured_traffic(workload, P, group) if bound == "hbm" else None,
             "avg_launch_ms": avg_ms, "launches_timed": launches, "launches_per_step": per_step, what: per_launch}
@@ -384,7 +386,9 @@ def main():
     line["roofline"]["note"] = (
         "the kernel group with the largest time per step among all groups, against that group's own ceiling: HBM "
         "bytes for the image kernels, 32-bit vector-ALU lane-operations (20 per query x train row) for the matcher, "
-        "fp64 vector flops (45 per model x match Sampson test, ~3e4 per five-point solve) for the RANSAC kernels; "
+        "fp64 vector flops (~3e4 per five-point solve) for the five-point kernels, packed fp32 vector flops (45 per "
+        "model x match Sampson test, decided in single precision with a rounding bound, in fp64 when close) for the "
+        "scoring kernel; "
         "achieved = algorithmic work of an average launch / mean launch duration by HIP events on the kernel's "
         "stream inside the timed steps; traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the "
         "configuration matches")
