@@ -345,20 +345,25 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 TB = (above(S, Ci) | above(N, Ci)) & (above(E, Ci) | above(W, Ci)) & cm;
             }
             const uint32_t T = TD | TB;
-            const unsigned long long m0 = __ballot(T & 0x80u), m1 = __ballot(T & 0x8000u);
-            const unsigned long long m2 = __ballot(T & 0x800000u), m3 = __ballot(T & 0x80000000u);
-            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
-            const uint32_t tot = c0 + c1 + c2 + (uint32_t)__popcll(m3);
+            // Entries go to the queue in pixel order (a lane's up to four entries side by side): a
+            // group of 32 consecutive entries then spans little more than one tile row, so the byte
+            // reads of the ring stage fall into distinct LDS banks or into the same dword.  (With
+            // one ballot per byte position a group gathered every fourth pixel of four or five
+            // rows, whose 20-dword pitch folds them onto the same banks.)
+            const uint32_t pc = (uint32_t)__popc(T & 0x80808080u);
+            const unsigned long long b0 = __ballot(pc & 1u), b1 = __ballot(pc & 2u), b2 = __ballot(pc & 4u);
+            const uint32_t tot = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
             if (tot == 0) continue;   // wave-uniform
             uint32_t qb = 0;
             if (lane == 0) qb = lds_fetch_add(&n1, tot);
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            uint32_t sl = slot(b0, qb) + 2u * slot(b1, 0u) + 4u * slot(b2, 0u);   // entries of the lanes below
             const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
             // one entry per passing pixel: the darker-ring copy if that polarity passed, else the plain one
-            if (T & 0x80u) q1[slot(m0, qb)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FP_N) + pos);
-            if (T & 0x8000u) q1[slot(m1, qb + c0)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FP_N) + (pos + 1));
-            if (T & 0x800000u) q1[slot(m2, qb + c0 + c1)] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FP_N) + (pos + 2));
-            if (T & 0x80000000u) q1[slot(m3, qb + c0 + c1 + c2)] = (uint16_t)(__umul24(TD >> 31, FP_N) + (pos + 3));
+            if (T & 0x80u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FP_N) + pos);
+            if (T & 0x8000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FP_N) + (pos + 1));
+            if (T & 0x800000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FP_N) + (pos + 2));
+            if (T & 0x80000000u) q1[sl] = (uint16_t)(__umul24(TD >> 31, FP_N) + (pos + 3));
             // pixels that passed in both polarities (saddle-like neighbourhoods, about one in a
             // hundred entries): a second entry for the brighter-ring polarity
             const uint32_t both = TD & TB;
