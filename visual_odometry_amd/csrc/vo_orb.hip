@@ -269,11 +269,12 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     constexpr int cx0 = 6;
     constexpr int g0 = cx0 >> 2, ng = ((cx0 + FT_W + 1) >> 2) - g0 + 1;   // dword groups that hold score columns
     const int max_sx = L.w - kEdge - (x0 - 1), max_sy = L.h - kEdge - (y0 - 1);   // inclusive bounds
-    if (tid < ng) {
-        // pre-test result bits (7, 15, 23, 31: pixels 0..3) of the group's columns that are score
+    if (tid < FP_W / 4) {
+        // pre-test result bits (7, 15, 23, 31: pixels 0..3) of a dword column's pixels that are score
         // columns 0 .. lim_x: the same for every row, so looked up instead of recomputed per group
+        // (zero for the dword columns left and right of the score region)
         const int lim_x = min(FT_W + 1, max_sx);
-        const int sx0 = 4 * (g0 + tid) - cx0;
+        const int sx0 = 4 * tid - cx0;
         const int lo = max(-sx0, 0), hi = min(lim_x - sx0 + 1, 4);
         const uint32_t nib = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
         colmask[tid] = ((nib & 1u) << 7) | ((nib & 2u) << 14) | ((nib & 4u) << 21) | ((nib & 8u) << 28);
@@ -328,19 +329,23 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
             return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
         };
-        for (int i0 = 0; i0 < ng * FS_H; i0 += 256) {
+        // A lane takes the dword at tile offset 3 * PD + i: consecutive lanes read consecutive
+        // dwords whatever the row, so no read of this stage meets a bank conflict (the three
+        // dword columns per row outside the score region ride along with an empty column mask).
+        static_assert(g0 >= 1 && g0 + ng < PD, "the left and right neighbour dwords stay inside the row");
+        for (int i0 = 0; i0 < PD * FS_H; i0 += 256) {
             const int i = i0 + tid;
-            const int sy = i / ng, gk = i - sy * ng, gi = g0 + gk;
+            const int sy = i / PD, gi = i - sy * PD;
             uint32_t TD = 0, TB = 0;   // bits 7, 15, 23, 31: pixels 0..3 of the group pass (darker / brighter ring)
             if (sy <= lim_y) {
-                const int idx = (sy + 3) * PD + gi;
+                const int idx = 3 * PD + i;
                 const uint32_t C = px32[idx], Lw = px32[idx - 1], Rw = px32[idx + 1];
                 const uint32_t S = px32[idx + 3 * PD], N = px32[idx - 3 * PD];
                 const uint32_t Ci = ix32[idx], Li = ix32[idx - 1], Ri = ix32[idx + 1];
                 const uint32_t Si = ix32[idx + 3 * PD], Ni = ix32[idx - 3 * PD];
                 const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1), E = __builtin_amdgcn_alignbyte(Rw, C, 3);
                 const uint32_t Wi = __builtin_amdgcn_alignbyte(Ci, Li, 1), Ei = __builtin_amdgcn_alignbyte(Ri, Ci, 3);
-                const uint32_t cm = colmask[gk];
+                const uint32_t cm = colmask[gi];
                 TD = (above(C, Si) | above(C, Ni)) & (above(C, Ei) | above(C, Wi)) & cm;
                 TB = (above(S, Ci) | above(N, Ci)) & (above(E, Ci) | above(W, Ci)) & cm;
             }
