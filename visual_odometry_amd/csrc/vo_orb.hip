@@ -175,7 +175,11 @@ constexpr int FS_W = FP_W, FS_H = FT_H + 2;   // score tile (1-px halo), logical
                                               // so that a queue entry (byte offset into the pixel tile) also addresses the score
 constexpr int FQ_N = FS_H * (FT_W + 2);     // positions whose score is needed
 
-constexpr int FP_N = FP_H * FP_W;            // bytes of the pixel tile; its inverted copy (255 - p) follows it
+constexpr int FP_N = FP_H * FP_W;            // bytes of the pixel tile
+// Offset of the tile's inverted copy (255 - p): 16 LDS banks away from the plain pixel, so that a
+// queue group's darker-ring entries (which read the copy) and the brighter-ring entries of the
+// pixels next to them do not meet on one bank.
+constexpr int FI_OFF = FP_N + 64;
 constexpr int FQ1_N = 2 * FQ_N;              // a position can enter the first queue once per polarity
 
 // Largest minimum over the sixteen 9-arcs of the ring (Bresenham circle of radius 3) around
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                                                    uint32_t tile_first, uint32_t ntiles, uint32_t tile_magic,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
                                                    unsigned long long* __restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) uint8_t px[2 * FP_N];   // the tile, then 255 - tile
+    __shared__ __attribute__((aligned(16))) uint8_t px[FI_OFF + FP_N];   // the tile, then 255 - tile at FI_OFF
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
     __shared__ __attribute__((aligned(16))) uint16_t q1[FQ1_N];
     __shared__ uint16_t q2[FQ_N];
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 int y = min(max(y0 - 4 + r, 0), L.h - 1);
                 uint32_t v = *reinterpret_cast<const uint32_t*>(base + ((uint32_t)__mul24(y, pitch) + col));
                 *reinterpret_cast<uint32_t*>(&px[r * FP_W + 4 * c]) = v;
-                *reinterpret_cast<uint32_t*>(&px[FP_N + r * FP_W + 4 * c]) = ~v;
+                *reinterpret_cast<uint32_t*>(&px[FI_OFF + r * FP_W + 4 * c]) = ~v;
             }
         }
     } else {
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             int x = min(ax0 + c, L.w - 1);
             const uint8_t v = base[(size_t)y * pitch + x];
             px[i] = v;
-            px[FP_N + i] = (uint8_t)~v;
+            px[FI_OFF + i] = (uint8_t)~v;
         }
     }
     __syncthreads();
@@ -314,12 +318,12 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     // and then (x + 128 - thr / 2) >> 1 has bit 7 set iff a - b > thr.  A 9-arc contains two
     // adjacent cardinals, i.e. (S | N) & (E | W) for one polarity.  A queue entry is the byte
     // offset of the pixel in the tile copy its polarity is scored on: the plain one for a
-    // brighter ring, the inverted one (+ FP_N) for a darker ring.
+    // brighter ring, the inverted one (+ FI_OFF) for a darker ring.
     {
         static_assert(kFastThr % 2 == 0 && kFastThr < 254, "the two-step average tests a - b >= thr + 1 exactly for even thr");
         constexpr int PD = FP_W / 4;   // dwords per LDS row
         const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
-        const uint32_t* ix32 = px32 + FP_N / 4;
+        const uint32_t* ix32 = px32 + FI_OFF / 4;
         const int lim_y = min(FS_H - 1, max_sy);
         constexpr uint32_t KT = (uint32_t)(128 - kFastThr / 2) * 0x01010101u;
         auto above = [](uint32_t a, uint32_t inv_b) -> uint32_t {   // bit 7 of a byte: a - b > thr
@@ -365,10 +369,10 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             uint32_t sl = slot(b0, qb) + 2u * slot(b1, 0u) + 4u * slot(b2, 0u);   // entries of the lanes below
             const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
             // one entry per passing pixel: the darker-ring copy if that polarity passed, else the plain one
-            if (T & 0x80u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FP_N) + pos);
-            if (T & 0x8000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FP_N) + (pos + 1));
-            if (T & 0x800000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FP_N) + (pos + 2));
-            if (T & 0x80000000u) q1[sl] = (uint16_t)(__umul24(TD >> 31, FP_N) + (pos + 3));
+            if (T & 0x80u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FI_OFF) + pos);
+            if (T & 0x8000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FI_OFF) + (pos + 1));
+            if (T & 0x800000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FI_OFF) + (pos + 2));
+            if (T & 0x80000000u) q1[sl] = (uint16_t)(__umul24(TD >> 31, FI_OFF) + (pos + 3));
             // pixels that passed in both polarities (saddle-like neighbourhoods, about one in a
             // hundred entries): a second entry for the brighter-ring polarity
             const uint32_t both = TD & TB;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         if (i < c1) {
             const uint32_t e = q1[i];
             const int best = ring_arc_contrast(&px[e]);
-            pos = e >= (uint32_t)FP_N ? e - (uint32_t)FP_N : e;
+            pos = e >= (uint32_t)FP_N ? e - (uint32_t)FI_OFF : e;
             pass = best > kFastThr;
             if (pass) sc[pos - sc_shift] = (uint8_t)(best - 1);
         }
