@@ -366,13 +366,18 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             uint32_t qb = 0;
             if (lane == 0) qb = lds_fetch_add(&n1, tot);
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            uint32_t sl = slot(b0, qb) + 2u * slot(b1, 0u) + 4u * slot(b2, 0u);   // entries of the lanes below
+            // byte offset of this lane's first entry: 2 * (qb + entries of the lanes below)
+            uint32_t sl = ((((slot(b2, 0u) << 1) + slot(b1, 0u)) << 1) + slot(b0, qb)) << 1;
             const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
+            auto put = [&](uint32_t entry) {
+                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(q1) + sl) = (uint16_t)entry;
+                sl += 2u;
+            };
             // one entry per passing pixel: the darker-ring copy if that polarity passed, else the plain one
-            if (T & 0x80u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FI_OFF) + pos);
-            if (T & 0x8000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FI_OFF) + (pos + 1));
-            if (T & 0x800000u) q1[sl++] = (uint16_t)(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FI_OFF) + (pos + 2));
-            if (T & 0x80000000u) q1[sl] = (uint16_t)(__umul24(TD >> 31, FI_OFF) + (pos + 3));
+            if (T & 0x80u) put(__umul24(__builtin_amdgcn_ubfe(TD, 7, 1), FI_OFF) + pos);
+            if (T & 0x8000u) put(__umul24(__builtin_amdgcn_ubfe(TD, 15, 1), FI_OFF) + (pos + 1));
+            if (T & 0x800000u) put(__umul24(__builtin_amdgcn_ubfe(TD, 23, 1), FI_OFF) + (pos + 2));
+            if (T & 0x80000000u) put(__umul24(TD >> 31, FI_OFF) + (pos + 3));
             // pixels that passed in both polarities (saddle-like neighbourhoods, about one in a
             // hundred entries): a second entry for the brighter-ring polarity
             const uint32_t both = TD & TB;
