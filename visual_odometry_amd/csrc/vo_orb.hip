@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
 
     // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed,
     // four horizontally adjacent pixels per lane, one per byte.  v_lerp_u8 averages bytes
-    // without carries between them: x = (a + (255 - b)) >> 1 (b read from the inverted copy)
-    // and then (x + 128 - thr / 2) >> 1 has bit 7 set iff a - b > thr.  A 9-arc contains two
+    // without carries between them: x = (a + (255 - b)) >> 1 (255 - b read from the inverted
+    // copy) and then (x + 128 - thr / 2) >> 1 has bit 7 set iff a - b > thr.  A 9-arc contains two
     // adjacent cardinals, i.e. (S | N) & (E | W) for one polarity.  A queue entry is the byte
     // offset of the pixel in the tile copy its polarity is scored on: the plain one for a
     // brighter ring, the inverted one (+ FI_OFF) for a darker ring.
@@ -325,10 +325,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
         const uint32_t* ix32 = px32 + FI_OFF / 4;
         const int lim_y = min(FS_H - 1, max_sy);
+        // One first average x = (C + 255 - b) >> 1 per cardinal b serves both polarities.  Darker
+        // ring, C - b > thr: bit 7 of (x + 128 - thr / 2) >> 1, exact.  Brighter ring, b - C > thr,
+        // i.e. C + 255 - b <= 254 - thr: x <= 127 - thr / 2, i.e. bit 7 of (x + 128 + thr / 2) >> 1
+        // clear - which also lets b - C == thr through (odd sums round down); the ring stage
+        // decides exactly, so the pre-test may pass a few pixels too many.
         constexpr uint32_t KT = (uint32_t)(128 - kFastThr / 2) * 0x01010101u;
-        auto above = [](uint32_t a, uint32_t inv_b) -> uint32_t {   // bit 7 of a byte: a - b > thr
-            return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, inv_b, 0u), KT, 0u);
-        };
+        constexpr uint32_t KB = (uint32_t)(128 + kFastThr / 2) * 0x01010101u;
+        auto avg = [](uint32_t a, uint32_t b) -> uint32_t { return __builtin_amdgcn_lerp(a, b, 0u); };
         // slot = wave-uniform base + number of passing lanes below this one (v_mbcnt pair)
         auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
             return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
@@ -343,15 +347,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             uint32_t TD = 0, TB = 0;   // bits 7, 15, 23, 31: pixels 0..3 of the group pass (darker / brighter ring)
             if (sy <= lim_y) {
                 const int idx = 3 * PD + i;
-                const uint32_t C = px32[idx], Lw = px32[idx - 1], Rw = px32[idx + 1];
-                const uint32_t S = px32[idx + 3 * PD], N = px32[idx - 3 * PD];
+                const uint32_t C = px32[idx];
                 const uint32_t Ci = ix32[idx], Li = ix32[idx - 1], Ri = ix32[idx + 1];
                 const uint32_t Si = ix32[idx + 3 * PD], Ni = ix32[idx - 3 * PD];
-                const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1), E = __builtin_amdgcn_alignbyte(Rw, C, 3);
                 const uint32_t Wi = __builtin_amdgcn_alignbyte(Ci, Li, 1), Ei = __builtin_amdgcn_alignbyte(Ri, Ci, 3);
+                const uint32_t xS = avg(C, Si), xN = avg(C, Ni), xE = avg(C, Ei), xW = avg(C, Wi);
                 const uint32_t cm = colmask[gi];
-                TD = (above(C, Si) | above(C, Ni)) & (above(C, Ei) | above(C, Wi)) & cm;
-                TB = (above(S, Ci) | above(N, Ci)) & (above(E, Ci) | above(W, Ci)) & cm;
+                TD = (avg(xS, KT) | avg(xN, KT)) & (avg(xE, KT) | avg(xW, KT)) & cm;
+                TB = ~((avg(xS, KB) & avg(xN, KB)) | (avg(xE, KB) & avg(xW, KB))) & cm;
             }
             const uint32_t T = TD | TB;
             // Entries go to the queue in pixel order (a lane's up to four entries side by side): a
