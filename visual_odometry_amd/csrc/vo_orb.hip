@@ -217,6 +217,29 @@ __device__ __forceinline__ uint32_t lds_fetch_add(uint32_t* p, uint32_t v) {
     return r;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront (all lanes active): four shifts inside
+// the rows of 16 lanes, then the totals of rows 0 and 2 into rows 1 and 3 and that of the
+// lower half into the upper one.  Six DPP adds; written out because each must wait two
+// states for the previous one's result.
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return x;
+}
+
 // Appends `val` for the lanes with pass == true to an LDS queue: one atomic per wavefront.
 __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, uint32_t* cnt, int lane) {
     unsigned long long m = __ballot(pass);
@@ -333,10 +356,6 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         constexpr uint32_t KT = (uint32_t)(128 - kFastThr / 2) * 0x01010101u;
         constexpr uint32_t KB = (uint32_t)(128 + kFastThr / 2) * 0x01010101u;
         auto avg = [](uint32_t a, uint32_t b) -> uint32_t { return __builtin_amdgcn_lerp(a, b, 0u); };
-        // slot = wave-uniform base + number of passing lanes below this one (v_mbcnt pair)
-        auto slot = [&](unsigned long long m, uint32_t first) -> uint32_t {
-            return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, first));
-        };
         // A lane takes the dword at tile offset 3 * PD + i: consecutive lanes read consecutive
         // dwords whatever the row, so no read of this stage meets a bank conflict (the three
         // dword columns per row outside the score region ride along with an empty column mask).
@@ -357,20 +376,20 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 TB = ~((avg(xS, KB) & avg(xN, KB)) | (avg(xE, KB) & avg(xW, KB))) & cm;
             }
             const uint32_t T = TD | TB;
-            // Entries go to the queue in pixel order (a lane's up to four entries side by side): a
-            // group of 32 consecutive entries then spans little more than one tile row, so the byte
-            // reads of the ring stage fall into distinct LDS banks or into the same dword.  (With
-            // one ballot per byte position a group gathered every fourth pixel of four or five
-            // rows, whose 20-dword pitch folds them onto the same banks.)
+            // Entries go to the queue in pixel order (a lane's up to four entries side by side, its
+            // first slot from a prefix sum over the lanes' entry counts): a group of 32 consecutive
+            // entries then spans little more than one tile row, so the byte reads of the ring
+            // stage fall into distinct LDS banks or into the same dword.  (With one ballot per
+            // byte position a group gathered every fourth pixel of four or five rows, whose
+            // 20-dword pitch folds them onto the same banks.)
             const uint32_t pc = (uint32_t)__popc(T & 0x80808080u);
-            const unsigned long long b0 = __ballot(pc & 1u), b1 = __ballot(pc & 2u), b2 = __ballot(pc & 4u);
-            const uint32_t tot = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+            const uint32_t upto = wave_prefix_sum(pc);   // entries of this lane and the lanes below
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
             if (tot == 0) continue;   // wave-uniform
             uint32_t qb = 0;
             if (lane == 0) qb = lds_fetch_add(&n1, tot);
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            // byte offset of this lane's first entry: 2 * (qb + entries of the lanes below)
-            uint32_t sl = ((((slot(b2, 0u) << 1) + slot(b1, 0u)) << 1) + slot(b0, qb)) << 1;
+            uint32_t sl = (qb + upto - pc) << 1;   // byte offset of this lane's first entry
             const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
             auto put = [&](uint32_t entry) {
                 *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(q1) + sl) = (uint16_t)entry;
