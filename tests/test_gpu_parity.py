@@ -151,7 +151,26 @@ IMAGES = {
     "narrow": lambda: synth.frame_pair(10, height=203, width=75)[0],
     "low": lambda: synth.frame_pair(11, height=66, width=517)[1],
     "edge68": lambda: synth.frame_pair(12, height=117, width=131)[0],
+    # grey levels 20 and 21 apart in one- to three-pixel blocks: ring-minus-centre differences sit on
+    # both sides of the FAST threshold (20) and exactly on it, in both polarities
+    "threshold": lambda: _threshold_steps(13, 240, 333),
 }
+
+
+def _threshold_steps(seed, height, width):
+    rng = np.random.default_rng(seed)
+    levels = np.array([70, 90, 91, 110, 111, 131, 132, 152], np.uint8)
+    img = np.zeros((height, width), np.uint8)
+    y = 0
+    while y < height:
+        bh = int(rng.integers(1, 4))
+        x = 0
+        while x < width:
+            bw = int(rng.integers(1, 4))
+            img[y:y + bh, x:x + bw] = levels[rng.integers(0, len(levels))]
+            x += bw
+        y += bh
+    return img
 
 
 @pytest.mark.parametrize("name", list(IMAGES))
@@ -177,7 +196,7 @@ def test_pyramid_blur_fast_stages(ctx, oracle, name):
 
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 1000), ("checker", 2000), ("checker", 100),
                                         ("kitti", 4000), ("odd", 500), ("synth640", 37), ("narrow", 300),
-                                        ("low", 300), ("edge68", 500)])
+                                        ("low", 300), ("edge68", 500), ("threshold", 800)])
 def test_orb_detect_bit_exact(ctx, oracle, name, nfeat):
     img = IMAGES[name]()
     gk, gd = ctx.orb_detect(img, nfeat)
