@@ -441,12 +441,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     const uint32_t c2 = n2;
 
     // 3x3 non-max suppression + border filter on the interior (only corners need the look-up)
+    const uint32_t nms_w = (uint32_t)max(min(FT_W, L.w - kEdge - x0), 0), nms_h = (uint32_t)max(min(FT_H, L.h - kEdge - y0), 0);
     for (uint32_t i = tid; i < c2; i += 256) {
         const uint16_t pos = q2[i];
         const int sy = pos / FP_W - 3, sx = pos - (sy + 3) * FP_W - cx0;
-        int ix = sx - 1, iy = sy - 1;
-        int X = x0 + ix, Y = y0 + iy;
-        if (ix < 0 || iy < 0 || ix >= FT_W || iy >= FT_H || X >= L.w - kEdge || Y >= L.h - kEdge) continue;
+        const int ix = sx - 1, iy = sy - 1;
+        const int X = x0 + ix, Y = y0 + iy;
+        // inside the tile and inside the level's 31-px border: one unsigned compare per axis
+        if ((uint32_t)ix >= nms_w || (uint32_t)iy >= nms_h) continue;
         const uint8_t* s = &sc[pos - sc_shift];
         // all nine reads issued together (a short-circuit chain is nine LDS round trips in a row)
         const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-FS_W - 1], n3 = s[-FS_W], n4 = s[-FS_W + 1], n5 = s[FS_W - 1],
