@@ -120,6 +120,35 @@ def make_frames(cfg, rank, n_distinct, sparse):
     return [f for ab in pairs for f in ab]
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pair_roofline(h, w, work, pairs, step_s):
+    """The pair-level bound: the time one step's algorithmic work would take on each of the three
+    ceilings the path touches, and the largest of them against the measured step.  Bytes of the
+    image stages per pair = 2 images x Sum(level pixels) x (FAST read + pyramid write + blur read +
+    blur write); matcher 20 lane-operations per query x train row; scoring 45 flops per model x
+    match.  The matcher term is also given at 16 lanes per clock and SIMD (3.93e13 lane-ops/s), the
+    figure a plain count of the vector ALUs gives, beside the 32 the fast instruction class reaches."""
+    P_px = sum(level_pixels(h, w))
+    t_hbm = pairs * 2 * 4 * P_px / (PEAK["hbm"][0] * 1e9)
+    t_match = work["knn2"] / (PEAK["valu_int"][0] * 1e12)
+    t_score = work["ransac_score"] / (PEAK["valu_fp64"][0] * 1e12)
+    terms = {"hbm": t_hbm, "valu_int": t_match, "valu_fp64": t_score}
+    binding = max(terms, key=terms.get)
+    return {"image_bytes_per_pair": 2 * 4 * P_px, "ms_at_hbm_peak": 1e3 * t_hbm, "ms_at_int_lane_peak": 1e3 * t_match,
+            "ms_at_int_lane_peak_16_per_clock": 2e3 * t_match, "ms_at_fp64_peak": 1e3 * t_score,
+            "binding": binding, "ms_per_step": 1e3 * step_s, "frac": terms[binding] / step_s,
+            "frac_with_16_lanes_per_clock": max(t_hbm, 2 * t_match, t_score) / step_s}
+
+
 def cpu_baseline(frames, K, cfg, budget_s=12.0):
     """The CPU oracle (scalar port of the reference path) on a bounded sample of the same frames:
     one thread, then one frame pair per thread on the box's CPU share.  Both of the reference's
@@ -153,7 +182,7 @@ def cpu_baseline(frames, K, cfg, budget_s=12.0):
         n_done += 1
     dt = time.perf_counter() - t0
     out = {
-        "value": n_done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+        "value": n_done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"{n_done} of the workload's {n_pairs} distinct frame pairs, detect x2 + match + E-RANSAC + pose, "
                   f"{dt:.1f} s on one host thread (oracle/vo_oracle.cpp, g++ -O2; every frame detected twice, as the "
                   f"reference's loop does)",
@@ -313,6 +342,8 @@ def main():
                     help="contexts (streams + workspace) the steps rotate over; one context already "
                          "overlaps a batch's RANSAC rounds (side stream) with the next batch's detection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the step-latency distribution, the batch-size sweep and the host-buffer (PCIe-inclusive) rate")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-sequence", action="store_true")
     ap.add_argument("--no-aux-scene", action="store_true")
@@ -392,6 +423,73 @@ def main():
         "achieved = algorithmic work of an average launch / mean launch duration by HIP events on the kernel's "
         "stream inside the timed steps; traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the "
         "configuration matches")
+
+    line["pair_roofline"] = pair_roofline(H, W, work, P, dt / args.steps)
+
+    if not args.no_extras:
+        # Synchronous steps (a fence after each): the distribution of one batch's latency.  Larger
+        # than ms_per_step, where a batch's RANSAC tail runs beside the next batch's detection.
+        lat = []
+        for _ in range(min(max(args.steps, 5), 20)):
+            t0 = time.perf_counter()
+            run.step()
+            run.fence()
+            lat.append(1e3 * (time.perf_counter() - t0))
+        line["sync_step_ms"] = {"median": float(np.median(lat)), "p10": float(np.percentile(lat, 10)),
+                                "p90": float(np.percentile(lat, 90)), "steps": len(lat)}
+        if not cfg["sequence"]:
+            # Host buffers in, results out (rank-local, not overlapped): the image batch is copied from
+            # pinned host memory, the pipeline runs, the result records are copied back.  A caller
+            # that double-buffers hides the smaller of copy and compute; this is the plain sum.
+            host_imgs = run.imgs.cpu().pin_memory()
+            host_res = torch.empty(run.ress[0].shape, dtype=torch.uint8).pin_memory()
+            reps = max(3, args.steps // 4)
+            cp = []
+            for it in range(reps + 1):
+                if it == 1:
+                    run.fence()
+                    t0 = time.perf_counter()
+                tc = time.perf_counter()
+                run.imgs.copy_(host_imgs, non_blocking=True)
+                torch.cuda.synchronize()
+                cp.append(time.perf_counter() - tc)
+                run.call(ctx, run.ress[0])
+                ctx.sync()
+                host_res.copy_(run.ress[0], non_blocking=True)
+                torch.cuda.synchronize()
+            hd = (time.perf_counter() - t0) / reps
+            t = torch.tensor([hd], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            line["host_buffers_in_and_out"] = {
+                "value": P * world / float(t.item()), "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                "h2d_ms": 1e3 * float(np.mean(cp[1:])), "h2d_GBps": host_imgs.numel() / float(np.mean(cp[1:])) / 1e9,
+                "note": "copy of the image batch from pinned host memory + pipeline + copy of the results, one after "
+                        "the other; never `value`"}
+            del host_imgs, host_res
+            # Batch sizes below the headline's: a batch has to fill 256 CUs and amortise a chain of
+            # some sixty launches.
+            sweep = []
+            for b in (1, 8, 64, 256):
+                if b >= P:
+                    continue
+                rb = Runner(torch, dist, capi, [ctx], cfg, frames, b, K, world)
+                for _ in range(3):
+                    rb.step()
+                rb.fence()
+                nb = max(args.steps, 40 if b <= 8 else 20)
+                t0 = time.perf_counter()
+                for _ in range(nb):
+                    rb.step()
+                rb.fence()
+                bd = (time.perf_counter() - t0) / nb
+                t = torch.tensor([bd], dtype=torch.float64, device="cuda")
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sweep.append({"pairs_per_step_per_gpu": b, "value": b * world / float(t.item()),
+                              "ms_per_step": 1e3 * float(t.item())})
+                del rb
+            line["batch_sweep"] = sweep
 
     if aux_frames is not None:
         # The other end of the scene range: few corners, ~40 % inliers (many RANSAC rounds).  Short

@@ -6,7 +6,7 @@ set -e
 for round in 1 2; do
   for so in "$@"; do
     cp "$so" visual_odometry_amd/libvo_hip.so
-    timeout -k 10 120 python3 bench.py --no-hamming --no-cpu-baseline --no-sequence --steps 40 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err
+    timeout -k 10 120 python3 bench.py --no-hamming --no-cpu-baseline --no-extras --no-sequence --steps 40 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err
     python3 - "$so" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))

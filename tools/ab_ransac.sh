@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B timing of library builds on the RANSAC-heavy workloads: tools/ab_ransac.sh ab_libs/A.so ab_libs/B.so ...
 set -e
-S="--no-hamming --no-cpu-baseline --no-sequence --no-aux-scene --no-dropin"
+S="--no-hamming --no-cpu-baseline --no-extras --no-sequence --no-aux-scene --no-dropin"
 for round in 1 2; do
   for so in "$@"; do
     cp "$so" visual_odometry_amd/libvo_hip.so

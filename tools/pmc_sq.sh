@@ -8,5 +8,5 @@ mkdir -p $OUT
 cd /tmp
 A="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_ANY"
 B="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-timeout -s KILL 300 rocprofv3 --pmc $A --output-format csv -d $OUT/a -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-sequence --no-aux-scene --no-dropin --no-scene-counters
-timeout -s KILL 300 rocprofv3 --pmc $B --output-format csv -d $OUT/b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-sequence --no-aux-scene --no-dropin --no-scene-counters
+timeout -s KILL 300 rocprofv3 --pmc $A --output-format csv -d $OUT/a -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-extras --no-sequence --no-aux-scene --no-dropin --no-scene-counters
+timeout -s KILL 300 rocprofv3 --pmc $B --output-format csv -d $OUT/b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-extras --no-sequence --no-aux-scene --no-dropin --no-scene-counters
