@@ -32,7 +32,7 @@ tests/cpp/test_callers: tests/cpp/test_callers.cpp visual_odometry_amd/libvisual
 
 # command-line front end (the reference tool's flags and output)
 visual_odometry_amd/vo_main: apps/vo_main.cpp visual_odometry_amd/libvisual_odometry_hip.so
-	$(CXX) -std=c++20 -O2 -Iinclude -o $@ apps/vo_main.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,visual_odometry_amd
+	$(CXX) -std=c++20 -O2 -Iinclude -pthread -o $@ apps/vo_main.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,visual_odometry_amd
 
 visual_odometry_amd/vo_benchmark: apps/vo_benchmark.cpp visual_odometry_amd/libvisual_odometry_hip.so
 	$(CXX) -std=c++20 -O2 -Iinclude -o $@ apps/vo_benchmark.cpp -Lvisual_odometry_amd -lvisual_odometry_hip -lvo_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,visual_odometry_amd

@@ -3,12 +3,14 @@
 // consecutive frames and writes the trajectory JSON.  Frames go to the GPU a batch at a time
 // (process_sequence), so every frame is decoded, uploaded and detected once.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <optional>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <vector>
 
 #include <visual_odometry/image_loader.hpp>
@@ -27,6 +29,7 @@ struct options {
     int max_frames{0};
     int batch{64};   // frame pairs per GPU call
     int gpus{1};     // GPUs the pairs of a batch are split over (devices 0 .. gpus - 1)
+    int decode_threads{(int)std::clamp(std::thread::hardware_concurrency(), 1u, 16u)};   // host threads that decode a batch's files
 };
 
 void usage(std::string_view program) {
@@ -39,6 +42,7 @@ void usage(std::string_view program) {
               << "  --max-frames <n>   Maximum frames to process (default: all)\n"
               << "  --batch <n>        Frame pairs per GPU call (default: 64)\n"
               << "  --gpus <n>         GPUs to split every batch over, devices 0..n-1 (default: 1)\n"
+              << "  --decode-threads <n>  Host threads that decode a batch's image files (default: the host's cores, at most 16)\n"
               << "  --help             Show this help message\n";
 }
 
@@ -57,6 +61,7 @@ auto parse(int argc, char** argv) -> std::optional<options> {
         else if (a == "--matcher" && (v = value())) o.matcher = v;
         else if (a == "--max-frames" && (v = value())) o.max_frames = std::atoi(v);
         else if (a == "--batch" && (v = value())) o.batch = std::max(1, std::atoi(v));
+        else if (a == "--decode-threads" && (v = value())) o.decode_threads = std::max(1, std::atoi(v));
         else if (a == "--gpus" && (v = value())) o.gpus = std::max(1, std::atoi(v));
         else {
             std::cerr << "Unknown argument: " << a << "\n";
@@ -150,14 +155,24 @@ int main(int argc, char** argv) {
         // belongs to, as in the reference (ref:src/main.cpp:152-158)
         std::vector<std::optional<cv::Mat>> frames(n_pairs + 1);
         std::vector<std::string> load_error(n_pairs + 1);
-        for (size_t k = 0; k <= n_pairs; ++k) {
-            if (k == 0 && have_carried) {
-                frames[0] = carried;
-                continue;
-            }
-            auto img = loader->load_image(first + k);
-            if (img.has_value() && !img.value().empty()) frames[k] = img.value();
-            else load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+        if (have_carried) frames[0] = carried;
+        // Decoding is what the host spends its time on (milliseconds per frame against
+        // microseconds on the GPU), and frames decode independently: the batch's files are
+        // shared out over the host's cores, each worker taking the next index.
+        {
+            std::atomic<size_t> next{have_carried ? size_t{1} : size_t{0}};
+            auto decode = [&] {
+                for (size_t k = next.fetch_add(1); k <= n_pairs; k = next.fetch_add(1)) {
+                    auto img = loader->load_image(first + k);
+                    if (img.has_value() && !img.value().empty()) frames[k] = img.value();
+                    else load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+                }
+            };
+            size_t const workers = std::min<size_t>({(size_t)opt->decode_threads, n_pairs + 1});
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < workers; ++w) pool.emplace_back(decode);
+            decode();
+            for (auto& t : pool) t.join();
         }
         std::vector<std::optional<vo::sequence_step>> steps(n_pairs);
         // maximal runs of loaded frames of one size and type go to the GPU in one call each
