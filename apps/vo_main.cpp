@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <future>
 #include <iomanip>
 #include <iostream>
 #include <optional>
@@ -147,33 +148,49 @@ int main(int argc, char** argv) {
         st.motion = vo::estimate_motion(m.points1, m.points2, *intrinsics);
         return st;
     };
+    // Decoding is what the host spends its time on (milliseconds per frame against microseconds
+    // on the GPU), and frames decode independently: a batch's files are shared out over the host's
+    // cores, each worker taking the next index, and the next batch is decoded while the GPU works
+    // on this one.
+    struct decoded_batch {
+        std::vector<std::optional<cv::Mat>> frames;   // frames first .. first + n_pairs (nullopt: failed to load)
+        std::vector<std::string> load_error;
+    };
+    auto decode_batch = [&](size_t first, size_t n_pairs, bool skip_first) {
+        decoded_batch d{std::vector<std::optional<cv::Mat>>(n_pairs + 1), std::vector<std::string>(n_pairs + 1)};
+        std::atomic<size_t> next{skip_first ? size_t{1} : size_t{0}};   // frame 0 is the previous batch's last one
+        auto decode = [&] {
+            for (size_t k = next.fetch_add(1); k <= n_pairs; k = next.fetch_add(1)) {
+                auto img = loader->load_image(first + k);
+                if (img.has_value() && !img.value().empty()) d.frames[k] = img.value();
+                else d.load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+            }
+        };
+        size_t const workers = std::min<size_t>({(size_t)opt->decode_threads, n_pairs + 1});
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < workers; ++w) pool.emplace_back(decode);
+        decode();
+        for (auto& t : pool) t.join();
+        return d;
+    };
+    auto pairs_from = [&](size_t first) { return std::min((size_t)opt->batch, max_pairs - first); };
+    std::future<decoded_batch> ahead;
+    if (max_pairs > 0) ahead = std::async(std::launch::async, decode_batch, size_t{0}, pairs_from(0), false);
     std::optional<cv::Mat> carried;   // last frame of the previous batch (nullopt: it failed to load)
-    bool have_carried = false;
+    std::string carried_error;
     for (size_t first = 0; first < max_pairs; first += (size_t)opt->batch) {
-        size_t const n_pairs = std::min((size_t)opt->batch, max_pairs - first);
+        size_t const n_pairs = pairs_from(first);
         // frames first .. first + n_pairs; a frame that fails to load costs only the pairs it
         // belongs to, as in the reference (ref:src/main.cpp:152-158)
-        std::vector<std::optional<cv::Mat>> frames(n_pairs + 1);
-        std::vector<std::string> load_error(n_pairs + 1);
-        if (have_carried) frames[0] = carried;
-        // Decoding is what the host spends its time on (milliseconds per frame against
-        // microseconds on the GPU), and frames decode independently: the batch's files are
-        // shared out over the host's cores, each worker taking the next index.
-        {
-            std::atomic<size_t> next{have_carried ? size_t{1} : size_t{0}};
-            auto decode = [&] {
-                for (size_t k = next.fetch_add(1); k <= n_pairs; k = next.fetch_add(1)) {
-                    auto img = loader->load_image(first + k);
-                    if (img.has_value() && !img.value().empty()) frames[k] = img.value();
-                    else load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
-                }
-            };
-            size_t const workers = std::min<size_t>({(size_t)opt->decode_threads, n_pairs + 1});
-            std::vector<std::thread> pool;
-            for (size_t w = 1; w < workers; ++w) pool.emplace_back(decode);
-            decode();
-            for (auto& t : pool) t.join();
+        decoded_batch cur = ahead.get();
+        std::vector<std::optional<cv::Mat>>& frames = cur.frames;
+        std::vector<std::string>& load_error = cur.load_error;
+        if (first > 0) {
+            frames[0] = carried;
+            load_error[0] = carried_error;
         }
+        if (size_t const next_first = first + (size_t)opt->batch; next_first < max_pairs)
+            ahead = std::async(std::launch::async, decode_batch, next_first, pairs_from(next_first), true);
         std::vector<std::optional<vo::sequence_step>> steps(n_pairs);
         // maximal runs of loaded frames of one size and type go to the GPU in one call each
         size_t k = 0;
@@ -207,7 +224,7 @@ int main(int argc, char** argv) {
             account(i, *steps[j]);
         }
         carried = frames[n_pairs];
-        have_carried = true;
+        carried_error = load_error[n_pairs];
     }
 
     std::cout << "\nProcessed " << max_pairs << " pairs, " << valid_motions << " valid motions\n";
