@@ -164,6 +164,27 @@ def test_trajectory_and_loader(dataset):
     assert lines[-2] == "pairs 15"
 
 
+def test_decoders_survive_damaged_files(dataset, tmp_path):
+    """The PNG / PNM / JPEG decoders under AddressSanitizer and UBSan on the fixture files with random
+    damage (flipped bytes, broken headers, truncation, spliced tails): a file may be refused, nothing
+    may be read or written out of bounds."""
+    d, expect = dataset
+    exe = str(tmp_path / "fuzz_decoders")
+    build = subprocess.run(
+        ["g++", "-std=c++20", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-static-libasan",
+         "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "cpp", "fuzz_decoders.cpp"),
+         os.path.join(ROOT, "visual_odometry_amd", "csrc", "host", "vo_jpeg.cpp"), "-lz"],
+        capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "asan" in build.stderr.lower():
+        pytest.skip("no AddressSanitizer runtime for g++ here")
+    assert build.returncode == 0, build.stderr
+    seeds = [os.path.join(d, n) for n, want in sorted(expect.items()) if want is not None]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=4096")
+    run = subprocess.run([exe, "2500", "20251111"] + seeds, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr[-3000:]
+    assert run.stdout.startswith(f"{len(seeds)} of {len(seeds)} seed files")
+
+
 def test_python_api_host_side(dataset, tmp_path):
     """The Python module's host-side classes (names of the reference's bindings): loader contract,
     decoders equal to the C++ ones, trajectory algebra and JSON text."""

@@ -49,31 +49,37 @@ struct PngInfo {
 };
 
 // Undoes the per-row filter of one (sub-)image in place; rows are stride+1 bytes (filter byte first).
+// One loop per filter type (the type is a property of the row, not of the byte); the first
+// bpp_bytes bytes of a row have no left neighbour.
 auto unfilter(uint8_t* data, size_t rows, size_t stride, int bpp_bytes) -> bool {
     std::vector<uint8_t> zero(stride, 0);
     uint8_t const* prev = zero.data();
+    size_t const bpp = (size_t)bpp_bytes, head = std::min(bpp, stride);
     for (size_t y = 0; y < rows; ++y) {
         uint8_t* row = data + y * (stride + 1);
         int const ft = row[0];
         uint8_t* cur = row + 1;
-        for (size_t i = 0; i < stride; ++i) {
-            int const a = i >= (size_t)bpp_bytes ? cur[i - bpp_bytes] : 0;
-            int const b = prev[i];
-            int const c = i >= (size_t)bpp_bytes ? prev[i - bpp_bytes] : 0;
-            int pred = 0;
-            switch (ft) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) >> 1; break;
-                case 4: {
-                    int const p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
+        switch (ft) {
+            case 0: break;
+            case 1:
+                for (size_t i = head; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+                break;
+            case 2:
+                for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);
+                break;
+            case 3:
+                for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + (prev[i] >> 1));
+                for (size_t i = head; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - bpp] + prev[i]) >> 1));
+                break;
+            case 4:
+                for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);   // Paeth(0, b, 0) = b
+                for (size_t i = head; i < stride; ++i) {
+                    int const a = cur[i - bpp], b2 = prev[i], c = prev[i - bpp];
+                    int const p = a + b2 - c, pa = std::abs(p - a), pb = std::abs(p - b2), pc = std::abs(p - c);
+                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c)));
                 }
-                default: return false;
-            }
-            cur[i] = (uint8_t)(cur[i] + pred);
+                break;
+            default: return false;
         }
         prev = cur;
     }
@@ -175,6 +181,10 @@ auto decode_png(std::vector<uint8_t> const& file) -> cv::Mat {
         for (uint32_t y = 0; y < ph; ++y) {
             uint8_t const* row = raw.data() + off + (size_t)y * (stride + 1) + 1;
             uint8_t* out = img.ptr<uint8_t>((int)(ps.y0 + y * ps.dy));
+            if (ih.color == 0 && ih.depth == 8 && ps.dx == 1) {   // the common case: the row is the pixels
+                std::memcpy(out, row, pw);
+                continue;
+            }
             for (uint32_t x = 0; x < pw; ++x) out[ps.x0 + x * ps.dx] = png_gray(ih, row, x, palette);
         }
         off += (size_t)ph * (stride + 1);
