@@ -466,7 +466,47 @@ def main():
                 "h2d_ms": 1e3 * float(np.mean(cp[1:])), "h2d_GBps": host_imgs.numel() / float(np.mean(cp[1:])) / 1e9,
                 "note": "copy of the image batch from pinned host memory + pipeline + copy of the results, one after "
                         "the other; never `value`"}
-            del host_imgs, host_res
+            # The same with two image buffers: the copy of batch k + 1 runs on a stream of its own
+            # while batch k is in the pipeline.  (One context: a second one brings the process to
+            # more streams than it has hardware queues, and the copy then queues in front of kernels.)
+            bufs = [run.imgs, torch.empty_like(run.imgs)]
+            copy_stream = torch.cuda.Stream()
+            n_db = 2 * reps + 2
+            up_s = []
+
+            def upload(k):
+                tu = time.perf_counter()
+                with torch.cuda.stream(copy_stream):
+                    bufs[k % 2].copy_(host_imgs, non_blocking=True)
+                copy_stream.synchronize()
+                up_s.append(time.perf_counter() - tu)
+
+            def launch(k):
+                ctx.pipeline_pairs_dev(bufs[k % 2].data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
+                                       run.ress[0].data_ptr())
+
+            upload(0)
+            launch(0)
+            upload(1)
+            ctx.sync()
+            torch.cuda.synchronize()
+            up_s.clear()
+            t0 = time.perf_counter()
+            for k in range(1, n_db + 1):
+                launch(k)                  # batch k from the buffer filled during batch k - 1
+                upload(k + 1)              # the next one goes into the buffer batch k - 1 has left
+                ctx.sync()
+                host_res.copy_(run.ress[0], non_blocking=True)
+            torch.cuda.synchronize()
+            hd2 = (time.perf_counter() - t0) / n_db
+            t = torch.tensor([hd2], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            line["host_buffers_in_and_out"]["double_buffered"] = {
+                "value": P * world / float(t.item()), "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                "h2d_ms_beside_the_pipeline": 1e3 * float(np.mean(up_s)),
+                "note": "two image buffers, the upload of the next batch on a stream of its own beside the pipeline"}
+            del bufs, host_imgs, host_res
             # Batch sizes below the headline's: a batch has to fill 256 CUs and amortise a chain of
             # some sixty launches.
             sweep = []
