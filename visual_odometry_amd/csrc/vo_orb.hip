@@ -486,8 +486,10 @@ __device__ __forceinline__ uint32_t f2sortable(float f) {
 }
 
 // HarrisResponses: 7x7 block of Sobel-like gradients around (x0, y0), int32 sums, float32
-// response in OpenCV's operation order.  The 9x9 support is fetched as 9 rows of twelve
-// unaligned bytes and walked with a three-row register window.
+// response in OpenCV's operation order.  The 9x9 support is fetched as 9 rows of three dwords
+// from the 4-byte boundary at or below the window (a byte-misaligned 12-byte load costs the
+// texture addresser about twice an aligned one), shifted into place, and walked with a
+// three-row register window.
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x0, int y0) {
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
@@ -496,8 +498,13 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x0
     for (int r = 0; r < 9; ++r) {
         // one 12-byte load per row: the lanes' windows are scattered, so every load instruction
         // costs a cache-line look-up per lane whatever its width
-        const uint8_t* p = img + (size_t)(y0 - 4 + r) * pitch + (x0 - 4);
-        __builtin_memcpy(w[r], p, 12);
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(img + (size_t)(y0 - 4 + r) * pitch + (x0 - 4));
+        const uint32_t skew = (uint32_t)(addr & 3u);   // the nine bytes wanted start here; 9 + 3 <= 12
+        uint32_t t[3];
+        __builtin_memcpy(t, __builtin_assume_aligned(reinterpret_cast<const void*>(addr & ~(uintptr_t)3), 4), 12);
+        w[r][0] = __builtin_amdgcn_alignbyte(t[1], t[0], skew);
+        w[r][1] = __builtin_amdgcn_alignbyte(t[2], t[1], skew);
+        w[r][2] = __builtin_amdgcn_alignbyte(0u, t[2], skew);
     }
     auto px = [&](int r, int c) -> int { return (int)((w[r][c >> 2] >> (8 * (c & 3))) & 0xFFu); };
     int a = 0, b = 0, c = 0;
