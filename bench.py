@@ -466,37 +466,48 @@ def main():
                 "h2d_ms": 1e3 * float(np.mean(cp[1:])), "h2d_GBps": host_imgs.numel() / float(np.mean(cp[1:])) / 1e9,
                 "note": "copy of the image batch from pinned host memory + pipeline + copy of the results, one after "
                         "the other; never `value`"}
-            # The same with two image buffers: the copy of batch k + 1 runs on a stream of its own
-            # while batch k is in the pipeline.  (One context: a second one brings the process to
-            # more streams than it has hardware queues, and the copy then queues in front of kernels.)
+            # The same with two image buffers and two record buffers: the copy of batch k + 1 runs on a
+            # stream of its own while batch k is in the pipeline, and the per-call waits
+            # (vo_pipeline_wait) let batch k - 1's RANSAC rounds run on beside batch k's detection.
+            # (One context: a second one brings the process to more streams than it has hardware
+            # queues, and the copy then queues in front of kernels.)
             bufs = [run.imgs, torch.empty_like(run.imgs)]
-            copy_stream = torch.cuda.Stream()
+            ress = [run.ress[0], torch.empty_like(run.ress[0])]
+            copy_stream = torch.cuda.current_stream()   # (idle otherwise: a fifth stream would share a hardware queue)
             n_db = 2 * reps + 2
-            up_s = []
 
-            def upload(k):
-                tu = time.perf_counter()
+            main_stream = torch.cuda.ExternalStream(ctx.stream)   # the context's stream, to order it behind an upload
+            copied = [torch.cuda.Event(), torch.cuda.Event()]
+
+            def upload(k):                                  # asynchronous: the host does not wait for the copy
                 with torch.cuda.stream(copy_stream):
                     bufs[k % 2].copy_(host_imgs, non_blocking=True)
-                copy_stream.synchronize()
-                up_s.append(time.perf_counter() - tu)
+                    copied[k % 2].record(copy_stream)
 
             def launch(k):
+                main_stream.wait_event(copied[k % 2])       # the detection of batch k starts behind its upload
                 ctx.pipeline_pairs_dev(bufs[k % 2].data_ptr(), P, H, W, W, H * W, nfeat, 0.75, K, 1.0, 0.999, fixed,
-                                       run.ress[0].data_ptr())
+                                       ress[k % 2].data_ptr())
+                return ctx.pipeline_ticket()
 
             upload(0)
-            launch(0)
+            prev = launch(0)
             upload(1)
             ctx.sync()
             torch.cuda.synchronize()
-            up_s.clear()
+            upload(0)
+            prev = launch(0)
+            upload(1)
             t0 = time.perf_counter()
             for k in range(1, n_db + 1):
-                launch(k)                  # batch k from the buffer filled during batch k - 1
-                upload(k + 1)              # the next one goes into the buffer batch k - 1 has left
-                ctx.sync()
-                host_res.copy_(run.ress[0], non_blocking=True)
+                cur = launch(k)                             # batch k from the buffer filled during batch k - 1
+                ctx.pipeline_wait(prev, inputs=True)        # batch k - 1 has read its images:
+                upload(k + 1)                               # ... its buffer takes batch k + 1
+                ctx.pipeline_wait(prev, results=True)       # batch k - 1 is complete: its records go back
+                host_res.copy_(ress[(k - 1) % 2], non_blocking=True)
+                prev = cur
+            ctx.sync()
+            host_res.copy_(ress[n_db % 2], non_blocking=True)
             torch.cuda.synchronize()
             hd2 = (time.perf_counter() - t0) / n_db
             t = torch.tensor([hd2], dtype=torch.float64, device="cuda")
@@ -504,8 +515,10 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             line["host_buffers_in_and_out"]["double_buffered"] = {
                 "value": P * world / float(t.item()), "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
-                "h2d_ms_beside_the_pipeline": 1e3 * float(np.mean(up_s)),
-                "note": "two image buffers, the upload of the next batch on a stream of its own beside the pipeline"}
+                "note": "two image buffers and two record buffers; the next batch's upload runs beside the pipeline on "
+                        "another stream (the context's stream waits for the copy's event, the host does not); per-call "
+                        "waits (vo_pipeline_wait) instead of vo_sync"}
+            del ress
             del bufs, host_imgs, host_res
             # Batch sizes below the headline's: a batch has to fill 256 CUs and amortise a chain of
             # some sixty launches.

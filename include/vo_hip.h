@@ -208,6 +208,22 @@ int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int r
                           double threshold, double confidence, int fixed_iters,
                           vo_pair_result* d_results);
 
+/* Finer waits than vo_sync() for a caller that streams batches from host
+ * memory (no counterpart in the reference, whose loop is synchronous): every
+ * vo_pipeline_pairs_dev / vo_pipeline_sequence_dev call gets a ticket (1, 2, ...
+ * per context; vo_pipeline_ticket returns the last one, 0 before the first
+ * call).  vo_pipeline_wait blocks the host until that call has read its input
+ * images for the last time (VO_WAIT_INPUTS: the image buffer may be overwritten,
+ * e.g. by the upload of the batch after next) or has written all its result
+ * records (VO_WAIT_RESULTS) - without waiting for calls enqueued after it, so the
+ * RANSAC rounds of one batch keep running beside the detection of the next.
+ * Calls finish in order; the last VO_TICKET_RING tickets are tracked one by one,
+ * an older one is waited for through a younger call.  Unlike vo_sync() this does
+ * not report truncated keypoint lists; vo_pair_result.status carries them. */
+enum { VO_WAIT_INPUTS = 1, VO_WAIT_RESULTS = 2, VO_TICKET_RING = 4 };
+unsigned long long vo_pipeline_ticket(vo_ctx* ctx);
+int vo_pipeline_wait(vo_ctx* ctx, unsigned long long ticket, int what);
+
 /* match_images_orb (ref:src/image_matcher.cpp:71-81; orb_matcher::match_images,
  * ref:include/visual_odometry/image_matcher.hpp:52-55) for ONE pair of host
  * images, what the reference's main loop (ref:src/main.cpp:162) and benchmark

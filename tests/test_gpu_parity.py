@@ -721,6 +721,66 @@ def test_pipeline_back_to_back_calls_are_independent(ctx):
 
 
 @pytest.mark.gpu
+def test_pipeline_tickets_release_inputs_and_results_per_call(ctx):
+    """vo_pipeline_wait: after VO_WAIT_INPUTS for a call its image buffer may be overwritten while
+    the call's RANSAC rounds (and a younger call) are still running; after VO_WAIT_RESULTS its
+    records are final although a younger call is still in flight.  Tickets count up per context,
+    unknown ones are refused, old ones are waited for through a younger call."""
+    import torch
+    from visual_odometry_amd import capi
+    sets = []
+    for s_ in range(6):
+        frames = []
+        for p in range(3):
+            frames += list(synth.frame_pair(400 + 10 * s_ + p))
+        sets.append(np.stack(frames))
+
+    def launch(imgs, res):
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 3, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0, res.data_ptr())
+
+    def records(res):
+        return np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE).copy()
+
+    alone = []
+    for st in sets:
+        imgs = torch.from_numpy(st).cuda()
+        res = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        launch(imgs, res)
+        ctx.sync()
+        alone.append(records(res))
+    t0 = ctx.pipeline_ticket()
+    assert t0 >= len(sets)
+
+    bufs = [torch.from_numpy(sets[0]).cuda(), torch.from_numpy(sets[1]).cuda()]
+    outs = [torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in sets]
+    tickets = []
+    for k in range(len(sets)):
+        launch(bufs[k % 2], outs[k])
+        tickets.append(ctx.pipeline_ticket())
+        assert tickets[-1] == t0 + k + 1
+        if k >= 1:
+            # the buffer of call k - 1 takes the images of call k + 1 as soon as call k - 1 has read it
+            ctx.pipeline_wait(tickets[k - 1], inputs=True)
+            if k + 1 < len(sets):
+                bufs[(k + 1) % 2].copy_(torch.from_numpy(sets[k + 1]).cuda())
+            else:
+                bufs[(k + 1) % 2].fill_(7)
+            torch.cuda.synchronize()   # (the copy ran on torch's stream)
+            ctx.pipeline_wait(tickets[k - 1], results=True)
+            got = records(outs[k - 1])
+            assert got.tobytes() == alone[k - 1].tobytes(), f"call {k - 1}"
+    ctx.pipeline_wait(tickets[0], inputs=True, results=True)   # five calls old: served by a younger call's marks
+    ctx.pipeline_wait(tickets[-1], results=True)
+    assert records(outs[-1]).tobytes() == alone[-1].tobytes()
+    ctx.sync()
+    for bad in (0, tickets[-1] + 1):
+        with pytest.raises(RuntimeError, match="vo_pipeline_wait"):
+            ctx.pipeline_wait(bad, results=True)
+    with pytest.raises(RuntimeError, match="vo_pipeline_wait"):
+        ctx.pipeline_wait(tickets[-1])
+
+
+@pytest.mark.gpu
 def test_pipeline_sequence_equals_pairwise(ctx):
     """A sequence of frames gives, for each consecutive pair, exactly the record the pair
     pipeline gives for that pair (each frame is detected once instead of twice)."""

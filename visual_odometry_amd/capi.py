@@ -25,10 +25,11 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
-    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
+    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_ticket", "vo_pipeline_wait", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
+WAIT_INPUTS, WAIT_RESULTS = 1, 2                                 # vo_pipeline_wait (VO_WAIT_*)
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac",
             "ransac_solve", "ransac_score"]          # the last two split the RANSAC chain per round
 T_TOP = T_GROUPS[:8]
@@ -64,6 +65,9 @@ def load():
     lib.vo_ctx_stream.argtypes = [vp]
     lib.vo_ctx_stream.restype = vp
     lib.vo_sync.argtypes = [vp]
+    lib.vo_pipeline_ticket.argtypes = [vp]
+    lib.vo_pipeline_ticket.restype = C.c_ulonglong
+    lib.vo_pipeline_wait.argtypes = [vp, C.c_ulonglong, i]
     lib.vo_set_timing.argtypes = [vp, i]
     lib.vo_kernel_time_ms.argtypes = [vp, i, C.POINTER(i)]
     lib.vo_kernel_time_ms.restype = f
@@ -127,6 +131,16 @@ class Context:
 
     def sync(self):
         self._check(self.lib.vo_sync(self.h), "vo_sync")
+
+    def pipeline_ticket(self):
+        """Ticket of the device-resident pipeline call enqueued last (0: none yet)."""
+        return int(self.lib.vo_pipeline_ticket(self.h))
+
+    def pipeline_wait(self, ticket, inputs=False, results=False):
+        """Waits until the call with that ticket has read its images for the last time and / or
+        written its result records, without waiting for calls enqueued after it."""
+        self._check(self.lib.vo_pipeline_wait(self.h, int(ticket), (WAIT_INPUTS if inputs else 0) | (WAIT_RESULTS if results else 0)),
+                    "vo_pipeline_wait")
 
     def set_timing(self, on=True, groups=None):
         """Brackets the launches of the named kernel groups (default: all) with HIP events."""

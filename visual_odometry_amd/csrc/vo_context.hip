@@ -93,6 +93,14 @@ using namespace vo;
 
 extern "C" void vo_ctx_destroy(vo_ctx* c);
 
+static bool create_ticket_events(vo_ctx* c) {
+    for (int k = 0; k < VO_TICKET_RING; ++k)
+        if (hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_out[k], hipEventDisableTiming) != hipSuccess)
+            return false;
+    return true;
+}
+
 extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (!out) return VO_ERR_INVALID;
     *out = nullptr;
@@ -110,7 +118,7 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) != hipSuccess || !create_ticket_events(c)) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
@@ -145,6 +153,10 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
     if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
+    for (int k = 0; k < VO_TICKET_RING; ++k) {
+        if (c->ev_in[k]) (void)hipEventDestroy(c->ev_in[k]);
+        if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
+    }
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);

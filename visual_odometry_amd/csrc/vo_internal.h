@@ -71,6 +71,10 @@ struct vo_ctx {
     // keypoint records and the kNN table of its batch: ev_tail marks the end of those reads, and
     // the next kernel on the main stream that overwrites them waits for it (join_tail).
     hipEvent_t ev_tail = nullptr;
+    // Per-call completion marks for vo_pipeline_wait: ticket t uses slot t % VO_TICKET_RING;
+    // ev_in: the call's last read of its input images, ev_out: its last result record.
+    unsigned long long call_seq = 0;
+    hipEvent_t ev_in[VO_TICKET_RING] = {}, ev_out[VO_TICKET_RING] = {};
     bool tail_pending = false;
     // FAST on level 0 needs only the input images: it runs on a third stream beside the resize
     // chain that builds the other levels (ev_fork orders it after the counter reset, ev_fast0

@@ -51,6 +51,9 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
     uint8_t* desc = (uint8_t*)c->p_desc.p;
     int32_t* cnt = (int32_t*)c->p_cnt.p;
     if ((rc = orb_run(c, d_imgs, kps, desc, cap, cnt))) return rc;
+    // (the detector's last kernel follows every reader of the input images on this stream)
+    const unsigned long long ticket = c->call_seq + 1;
+    VO_HIP(c, hipEventRecord(c->ev_in[ticket % VO_TICKET_RING], c->stream));
     const size_t dstride = (size_t)pair_step * cap * 32;
     if ((rc = knn2_launch(c, desc, cnt, pair_step, cap, dstride, desc + (size_t)cap * 32, cnt + 1, cap, dstride, n_pairs,
                           (int32_t*)c->st_idx.p, (int32_t*)c->st_dist.p, max_features)))
@@ -74,7 +77,22 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
                          K, threshold, confidence, fixed_iters, d_results, nullptr, nullptr, nullptr, nullptr, nullptr,
                          0, true)))
         return rc;
+    VO_HIP(c, hipEventRecord(c->ev_out[ticket % VO_TICKET_RING], side));
+    c->call_seq = ticket;
     VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+extern "C" unsigned long long vo_pipeline_ticket(vo_ctx* c) { return c ? c->call_seq : 0ull; }
+
+extern "C" int vo_pipeline_wait(vo_ctx* c, unsigned long long ticket, int what) {
+    if (!c) return VO_ERR_INVALID;
+    if (ticket == 0 || ticket > c->call_seq || (what & ~(VO_WAIT_INPUTS | VO_WAIT_RESULTS)) || what == 0)
+        return fail(c, VO_ERR_INVALID, "vo_pipeline_wait: no such ticket or nothing to wait for");
+    VO_HIP(c, hipSetDevice(c->device));
+    // a slot that a younger call has taken over marks a later point of the same streams
+    if (what & VO_WAIT_INPUTS) VO_HIP(c, hipEventSynchronize(c->ev_in[ticket % VO_TICKET_RING]));
+    if (what & VO_WAIT_RESULTS) VO_HIP(c, hipEventSynchronize(c->ev_out[ticket % VO_TICKET_RING]));
     return VO_OK;
 }
 
