@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <exception>
 #include <future>
 #include <iomanip>
 #include <iostream>
@@ -161,9 +162,14 @@ int main(int argc, char** argv) {
         std::atomic<size_t> next{skip_first ? size_t{1} : size_t{0}};   // frame 0 is the previous batch's last one
         auto decode = [&] {
             for (size_t k = next.fetch_add(1); k <= n_pairs; k = next.fetch_add(1)) {
-                auto img = loader->load_image(first + k);
-                if (img.has_value() && !img.value().empty()) d.frames[k] = img.value();
-                else d.load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+                try {   // (an exception that left a worker thread would end the process)
+                    auto img = loader->load_image(first + k);
+                    if (img.has_value() && !img.value().empty()) d.frames[k] = img.value();
+                    else d.load_error[k] = img.has_value() ? std::string("Failed to load image") : img.error();
+                } catch (std::exception const& e) {
+                    d.frames[k].reset();
+                    d.load_error[k] = std::string("Failed to load image: ") + e.what();
+                }
             }
         };
         size_t const workers = std::min<size_t>({(size_t)opt->decode_threads, n_pairs + 1});
