@@ -1046,6 +1046,25 @@ void normalise_points(const float* p, int n, const double K[4], std::vector<doub
     }
 }
 
+// A total order on essential matrices that does not depend on how they were found: E and -E are
+// one model (the sign that makes the first entry of at least half the largest magnitude positive
+// is compared), entries are compared in storage order, differences below 1e-9 count as equal.
+bool model_before(const double* A, const double* B) {
+    auto sign_of = [](const double* E) {
+        double m = 0;
+        for (int i = 0; i < 9; ++i) m = std::max(m, std::fabs(E[i]));
+        for (int i = 0; i < 9; ++i)
+            if (std::fabs(E[i]) > 0.5 * m) return E[i] < 0 ? -1.0 : 1.0;
+        return 1.0;
+    };
+    const double sa = sign_of(A), sb = sign_of(B);
+    for (int i = 0; i < 9; ++i) {
+        const double d = sa * A[i] - sb * B[i];
+        if (std::fabs(d) > 1e-9) return d < 0;
+    }
+    return false;
+}
+
 // cv::findEssentialMat(..., RANSAC, prob, threshold, maxIters=1000, mask)
 // -> RANSACPointSetRegistrator::run.  fixed_iters > 0 disables the adaptive
 // iteration count and evaluates exactly that many hypotheses.
@@ -1067,8 +1086,10 @@ int find_essential(const float* p1, const float* p2, int n, const double K[4], d
     CvRng rng((uint64_t)-1);
     double Es[90];
     if (n == 5) {
-        // count == modelPoints: OpenCV returns every model stacked; only a
+        // count == modelPoints: one pass of the loop; OpenCV returns every model stacked, only a
         // single-model answer is usable downstream.
+        if (iters_run) *iters_run = 1;
+        if (samples_out) for (int i = 0; i < 5; ++i) samples_out[i] = i;   // the five points as they come, nothing is drawn
         int nm = five_point(m1.data(), m2.data(), Es);
         if (nm != 1) return 0;
         memcpy(E, Es, sizeof(double) * 9);
@@ -1088,21 +1109,32 @@ int find_essential(const float* p1, const float* p2, int n, const double K[4], d
         }
         if (samples_out) for (int i = 0; i < 5; ++i) samples_out[iter * 5 + i] = idx[i];
         int nm = five_point(s1, s2, Es);
+        // OpenCV walks the hypothesis' models in the order its polynomial solver happens to emit
+        // them and keeps the first with the most inliers.  That order is not reproducible (here the
+        // models come from several charts), so among a hypothesis' models with equally many inliers
+        // the one that comes first in a chart-independent order (model_before) is taken; the
+        // iteration bound only depends on the count.
+        int top = -1, top_k = -1;
+        std::vector<int> goods(nm);
         for (int k = 0; k < nm; ++k) {
             const double* Ek = Es + k * 9;
             int good = 0;
-            for (int i = 0; i < n; ++i) {
-                float e = sampson_err(Ek, m1[i * 2], m1[i * 2 + 1], m2[i * 2], m2[i * 2 + 1]);
-                cur[i] = e <= t;
-                good += cur[i];
+            for (int i = 0; i < n; ++i)
+                good += sampson_err(Ek, m1[i * 2], m1[i * 2 + 1], m2[i * 2], m2[i * 2 + 1]) <= t;
+            goods[k] = good;
+            if (good > top || (good == top && model_before(Ek, Es + top_k * 9))) {
+                top = good;
+                top_k = k;
             }
-            if (good > std::max(maxGood, 4)) {
-                std::swap(cur, best);
-                memcpy(bestE, Ek, sizeof bestE);
-                maxGood = good;
-                if (fixed_iters <= 0)
-                    niters = ransac_update_iters(confidence, (double)(n - good) / n, 5, niters);
-            }
+        }
+        if (top > std::max(maxGood, 4)) {
+            const double* Ek = Es + top_k * 9;
+            for (int i = 0; i < n; ++i)
+                best[i] = sampson_err(Ek, m1[i * 2], m1[i * 2 + 1], m2[i * 2], m2[i * 2 + 1]) <= t;
+            memcpy(bestE, Ek, sizeof bestE);
+            maxGood = top;
+            if (fixed_iters <= 0)
+                niters = ransac_update_iters(confidence, (double)(n - top) / n, 5, niters);
         }
     }
     if (iters_run) *iters_run = iter;

@@ -352,6 +352,70 @@ def test_sample_stream_with_few_points(ctx, oracle, n):
     assert gg == og and np.array_equal(gm, om)
 
 
+def _same_model_sets(ctx, oracle, p1, p2, K, samples):
+    """Index of the first minimal sample on which the GPU's five-point stage and the oracle's report
+    different model sets (E and -E are one model, 1e-7), or -1."""
+    fx, fy, cx, cy = K
+    n1 = np.stack([(p1[:, 0].astype(np.float64) - cx) / fx, (p1[:, 1].astype(np.float64) - cy) / fy], 1)
+    n2 = np.stack([(p2[:, 0].astype(np.float64) - cx) / fx, (p2[:, 1].astype(np.float64) - cy) / fy], 1)
+    x1, x2 = n1[samples], n2[samples]
+    gpu = ctx.five_point(x1, x2)
+
+    def one_sign(E):
+        out = []
+        for e in np.asarray(E).reshape(-1, 9):
+            big = np.flatnonzero(np.abs(e) > 0.5 * np.max(np.abs(e)))[0]
+            out.append(-e if e[big] < 0 else e)
+        return np.array(out).reshape(-1, 9)
+
+    for h in range(len(samples)):
+        A, B = one_sign(gpu[h]), one_sign(oracle.five_point(x1[h], x2[h]))
+        if len(A) != len(B) or (len(A) and max(np.min(np.max(np.abs(A - e), 1)) for e in B) > 1e-7):
+            return h
+    return -1
+
+
+def test_random_two_view_scenes(ctx, oracle):
+    """Geometric scenes instead of matched ORB points: planar and small-rotation scenes, noise-free
+    data on which every model of a hypothesis has all points as inliers (the winner among equals is
+    the first in a chart-independent order), 5 to 3000 matches, up to 90 % outliers, fixed and
+    adaptive hypothesis counts.  Sample sets, iteration count, inlier mask and model must be
+    identical - unless the two five-point stages report different model sets for one of the minimal
+    samples walked: both approximate the complete solution set (the oracle by the union over four
+    charts of the null space, the GPU by one chart and a second for odd model counts) and differ on
+    about one minimal sample in a thousand (tools/dbg_model_sets.py); such a scene is only counted.
+    Inputs that are not well-posed (pure rotation, a baseline of a five-hundredth of the depth, sets
+    full of repeated points) leave the minimal problem rank-deficient or nearly so and are skipped:
+    which of a cluster of solutions a solver reports there is a matter of its root finder
+    (tools/fuzz_ransac.py lists them)."""
+    done = incomplete = 0
+    for case in range(110):
+        rng = np.random.default_rng(1000003 * 7 + case)
+        p1, p2, K, thr, fixed, (kind, noise, baseline) = synth.two_view_scene(rng)
+        if kind in (3, 4) or baseline < 0.05:
+            continue
+        og, oE, om, oit, osamp = oracle.find_essential(p1, p2, K, threshold=thr, fixed_iters=fixed)
+        gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, K, threshold=thr, fixed_iters=fixed)
+        tag = f"case {case}: kind {kind} noise {noise} n {len(p1)} thr {thr} fixed {fixed}"
+        k = min(git, oit)
+        assert np.array_equal(gsamp[:k], osamp[:k]), tag          # one sample stream
+        done += 1
+        same = git == oit and gg == og and np.array_equal(gm, om)
+        if same and og > 0:
+            s = 1.0 if np.sum(gE * oE) > 0 else -1.0
+            same = np.max(np.abs(gE - s * oE)) < 1e-8
+        if not same:
+            assert len(p1) > 5 and _same_model_sets(ctx, oracle, p1, p2, K, osamp[:k]) >= 0, tag
+            incomplete += 1
+            continue
+        om_ = oracle.estimate_motion(p1, p2, K, threshold=thr, fixed_iters=fixed)
+        gm_ = ctx.estimate_motion(p1, p2, K, threshold=thr, fixed_iters=fixed)
+        assert bool(om_["valid"]) == bool(gm_["valid"]) and om_["inliers"] == gm_["inliers"], tag
+        if om_["valid"]:
+            assert np.max(np.abs(om_["R"] - gm_["R"])) < 1.7e-4 and np.max(np.abs(om_["t"] - gm_["t"])) < 1e-4, tag
+    assert done >= 40 and incomplete <= 2, (done, incomplete)
+
+
 @pytest.mark.parametrize("name", ["forward", "rotation"])
 def test_reference_motion_scenes(ctx, oracle, name):
     # ref:tests/test_motion_estimator.cpp:61-102 plus agreement with the oracle and the ground truth

@@ -250,7 +250,7 @@ __host__ __device__ int real_roots(const double* c, double* roots) {
                 // to a sign change the bracketed roots already are the two solutions.)
                 double mag = fabs(d[deg]), ab = fabs(b);
                 for (int i = deg - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-                pending = !changed && fabs(fb) <= 1e-6 * mag;
+                pending = !changed && fabs(fb) <= 1e-4 * mag;
             }
             if (b > a) {
                 a = b;
@@ -341,7 +341,7 @@ __host__ __device__ __forceinline__ int roots_level(const double* c, const doubl
             double mag = fabs(d[DEG]);
 #pragma unroll
             for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-            pending = !changed && fabs(fb) <= 1e-6 * mag;
+            pending = !changed && fabs(fb) <= 1e-4 * mag;
         }
         if (b > a) {
             a = b;
@@ -995,7 +995,7 @@ __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
             double ab = fabs(bT), mag = fabs(d[DEG]);
 #pragma unroll
             for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-            cT = fabs(fbT) <= 1e-6 * mag;
+            cT = fabs(fbT) <= 1e-4 * mag;
         }
         sh.ptype[h][g] = (uint8_t)((cA ? 1 : 0) | (cX ? 2 : 0) | (cT ? 4 : 0));
     }
@@ -1517,6 +1517,28 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     }
 }
 
+// A total order on essential matrices that does not depend on how they were found (OpenCV keeps
+// the first of a hypothesis' models with the most inliers in the order its polynomial solver
+// happens to emit them, which nothing else reproduces): E and -E are one model - the sign that
+// makes the first entry of at least half the largest magnitude positive is compared -, entries
+// are compared in storage order, differences below 1e-9 count as equal.
+__device__ bool model_before(const double* A, const double* B) {
+    double sa = 1.0, sb = 1.0, ma = 0.0, mb = 0.0;
+    for (int i = 0; i < 9; ++i) {
+        ma = fmax(ma, fabs(A[i]));
+        mb = fmax(mb, fabs(B[i]));
+    }
+    for (int i = 8; i >= 0; --i) {
+        if (fabs(A[i]) > 0.5 * ma) sa = A[i] < 0 ? -1.0 : 1.0;
+        if (fabs(B[i]) > 0.5 * mb) sb = B[i] < 0 ? -1.0 : 1.0;
+    }
+    for (int i = 0; i < 9; ++i) {
+        const double d = sa * A[i] - sb * B[i];
+        if (fabs(d) > 1e-9) return d < 0;
+    }
+    return false;
+}
+
 // RANSAC bookkeeping over one round, then the next round's samples: one workgroup per pair.
 // Both are serial by definition - the loop keeps the first model that beats every earlier one
 // and shrinks its iteration bound as it goes; the samples come off one cv::RNG stream with
@@ -1689,8 +1711,13 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
         const int stop = min(hr, max(max(s.niters - h0, 0), last + 1));
         if (stop > 0) s.iters_run = h0 + stop;
         if (best_h >= 0) {
-            const double* E = models + (((size_t)b * hr + best_h) * kMaxModels + s_hk[best_h]) * 9;
-            for (int i = 0; i < 9; ++i) s.bestE[i] = E[i];
+            // among the winning hypothesis' models with equally many inliers: the first in an order
+            // that does not depend on how the models were found (see model_before)
+            const double* Eh = models + ((size_t)b * hr + best_h) * kMaxModels * 9;
+            int k0 = s_hk[best_h];
+            for (int k = k0 + 1; k < s_nm[best_h]; ++k)
+                if (s_cnt[best_h * kMaxModels + k] == s_hb[best_h] && model_before(Eh + k * 9, Eh + k0 * 9)) k0 = k;
+            for (int i = 0; i < 9; ++i) s.bestE[i] = Eh[k0 * 9 + i];
         }
         if (stop < hr || h0 + hr >= s.niters || next_round <= 0) s.done = 1;
         s_stop = stop;

@@ -188,3 +188,46 @@ def descriptors(seed, n, dup_fraction=0.01):
     return d
 
 
+
+
+_TWO_VIEW_KS = [(517.3, 516.5, 318.6, 255.3), (718.856, 718.856, 607.1928, 185.2157), (1400.0, 1390.0, 960.0, 540.0),
+                (300.0, 320.0, 160.0, 120.0)]
+
+
+def _random_rotation(rng, max_deg):
+    v = rng.normal(size=3)
+    v /= np.linalg.norm(v)
+    a = np.deg2rad(rng.uniform(0, max_deg))
+    Kx = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+    return np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+
+
+def two_view_scene(rng):
+    """Random matched points of two views for RANSAC checks: (p1, p2, K, threshold, fixed_iters,
+    (kind, noise, baseline)).  kind 0: general scene, 1: planar, 2: small rotation, 3: pure rotation
+    (no translation), 4: a third of the matches are copies of the first.  5..3000 matches, pixel
+    noise 0..2, 0..90 % gross outliers, rotation up to 20 degrees, baseline 0.02..1 at depth 4..12."""
+    K = _TWO_VIEW_KS[rng.integers(len(_TWO_VIEW_KS))]
+    n = int(rng.choice([5, 6, 8, 12, 20, 50, 120, 300, 700, 1500, 3000]))
+    kind = rng.integers(5)
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 12, n)], 1)
+    if kind == 1:
+        X[:, 2] = 8.0 + 0.2 * X[:, 0]
+    R = _random_rotation(rng, 20.0 if kind != 2 else 3.0)
+    t = rng.normal(size=3)
+    t *= (0.0 if kind == 3 else rng.choice([0.02, 0.3, 1.0])) / max(np.linalg.norm(t), 1e-9)
+    Y = X @ R.T + t
+    fx, fy, cx, cy = K
+    p1 = np.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1)
+    p2 = np.stack([fx * Y[:, 0] / Y[:, 2] + cx, fy * Y[:, 1] / Y[:, 2] + cy], 1)
+    sig = rng.choice([0.0, 0.3, 1.0, 2.0])
+    p1 += rng.normal(0, sig, p1.shape)
+    p2 += rng.normal(0, sig, p2.shape)
+    out = rng.random(n) < rng.choice([0.0, 0.2, 0.5, 0.8, 0.9])
+    p2[out] += rng.uniform(-150, 150, (int(out.sum()), 2))
+    if kind == 4 and n > 10:
+        p1[1::3] = p1[0]
+        p2[1::3] = p2[0]
+    thr = float(rng.choice([0.3, 1.0, 3.0]))
+    fixed = int(rng.choice([0, 0, 0, 40, 600]))
+    return p1.astype(np.float32), p2.astype(np.float32), K, thr, fixed, (int(kind), float(sig), float(np.linalg.norm(t)))
