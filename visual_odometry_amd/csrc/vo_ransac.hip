@@ -244,10 +244,12 @@ __host__ __device__ int real_roots(const double* c, double* roots) {
                 }
             }
             if (j == 0 && k < np && fb != 0.0 && b > a) {
-                // A local extremum that touches zero to rounding level with no sign change on
-                // either side is a double root (exactly degenerate data, e.g. pure sideways
-                // translation): kept once the next piece is known to hold no root either.  (Next
-                // to a sign change the bracketed roots already are the two solutions.)
+                // A local extremum that comes within 1e-4 of zero (relative to the polynomial's
+                // magnitude there) with no sign change on either side is kept as a candidate once
+                // the next piece is known to hold no root either: a double root (exactly degenerate
+                // data, e.g. pure sideways translation) or a pair of close roots that the rounding
+                // of the elimination has merged away; the refinement on the constraints decides.
+                // (Next to a sign change the bracketed roots already are the two solutions.)
                 double mag = fabs(d[deg]), ab = fabs(b);
                 for (int i = deg - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
                 pending = !changed && fabs(fb) <= 1e-4 * mag;
@@ -991,7 +993,8 @@ __device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
         }
         bool cT = false;
         if (DEG == 10 && !right_open && fbT != 0.0) {
-            // a local extremum that touches zero to rounding level is a double root: keep it
+            // a local extremum within 1e-4 of zero, relative to the polynomial's magnitude there: a
+            // double root or a pair of close roots lost to the elimination's rounding - a candidate
             double ab = fabs(bT), mag = fabs(d[DEG]);
 #pragma unroll
             for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
