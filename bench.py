@@ -294,10 +294,19 @@ class Runner:
         avg_ms = sum(ms * n for ms, n in dom if n > 0) / max(launches, 1)
         for c in self.ctxs:
             c.set_timing(False)
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), avg_ms, launches
+        t = rank_max(torch, dist, dt)
+        return t, avg_ms, launches
+
+
+def rank_max(torch, dist, seconds):
+    """Maximum of a host-side duration over the ranks (the value itself without a process group).
+    The one-element tensor lives where the group's backend can reduce it: on the GPU for RCCL,
+    on the host for the gloo rehearsal."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def roofline_of(group, work_per_step, avg_ms, launches, steps, workload, P):
@@ -374,9 +383,19 @@ def main():
     import torch.distributed as dist
     from visual_odometry_amd import capi, sharding, synth
 
+    # Rehearsal on a box with fewer GPUs than ranks (VO_BENCH_SHARE_GPUS=1): ranks share the GPUs
+    # there are and the process group is gloo, because RCCL refuses two ranks on one device.
+    # It exercises every line of the multi-rank path except RCCL itself; its figures are not
+    # scaling measurements (the ranks compete for one GPU) and the line says so.
+    rehearsal = world > 1 and os.environ.get("VO_BENCH_SHARE_GPUS") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     K = synth.default_K(W, H)
     n_streams = max(1, args.streams)
     ctxs = [capi.Context(local_rank) for _ in range(n_streams)]
@@ -458,11 +477,9 @@ def main():
                 host_res.copy_(run.ress[0], non_blocking=True)
                 torch.cuda.synchronize()
             hd = (time.perf_counter() - t0) / reps
-            t = torch.tensor([hd], dtype=torch.float64, device="cuda")
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = rank_max(torch, dist, hd)
             line["host_buffers_in_and_out"] = {
-                "value": P * world / float(t.item()), "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                "value": P * world / t, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t,
                 "h2d_ms": 1e3 * float(np.mean(cp[1:])), "h2d_GBps": host_imgs.numel() / float(np.mean(cp[1:])) / 1e9,
                 "note": "copy of the image batch from pinned host memory + pipeline + copy of the results, one after "
                         "the other; never `value`"}
@@ -510,11 +527,9 @@ def main():
             host_res.copy_(ress[n_db % 2], non_blocking=True)
             torch.cuda.synchronize()
             hd2 = (time.perf_counter() - t0) / n_db
-            t = torch.tensor([hd2], dtype=torch.float64, device="cuda")
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = rank_max(torch, dist, hd2)
             line["host_buffers_in_and_out"]["double_buffered"] = {
-                "value": P * world / float(t.item()), "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                "value": P * world / t, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t,
                 "note": "two image buffers and two record buffers; the next batch's upload runs beside the pipeline on "
                         "another stream (the context's stream waits for the copy's event, the host does not); per-call "
                         "waits (vo_pipeline_wait) instead of vo_sync"}
@@ -536,11 +551,9 @@ def main():
                     rb.step()
                 rb.fence()
                 bd = (time.perf_counter() - t0) / nb
-                t = torch.tensor([bd], dtype=torch.float64, device="cuda")
-                if world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                sweep.append({"pairs_per_step_per_gpu": b, "value": b * world / float(t.item()),
-                              "ms_per_step": 1e3 * float(t.item())})
+                t = rank_max(torch, dist, bd)
+                sweep.append({"pairs_per_step_per_gpu": b, "value": b * world / t,
+                              "ms_per_step": 1e3 * t})
                 del rb
             line["batch_sweep"] = sweep
 
@@ -585,12 +598,10 @@ def main():
                                       res_seq.data_ptr())
         run.fence()
         sd = (time.perf_counter() - t0) / reps
-        t = torch.tensor([sd], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = rank_max(torch, dist, sd)
         line["sequence_mode"] = {"frames_per_step_per_gpu": F, "pairs_per_step_per_gpu": F - 1,
-                                 "value": (F - 1) * world / float(t.item()),
-                                 "unit": "frame-pairs/s", "ms_per_step": 1e3 * float(t.item()),
+                                 "value": (F - 1) * world / t,
+                                 "unit": "frame-pairs/s", "ms_per_step": 1e3 * t,
                                  "note": "consecutive frames, every frame detected once (vo_pipeline_sequence_dev); "
                                          "not the headline metric, which detects both images of every pair"}
         del seq, res_seq
@@ -624,10 +635,8 @@ def main():
             table = sharding.sharded_knn2(gpu_knn2, q_all, tr)   # kernel + (world > 1) the gather, every repetition
         run.fence()
         hd = (time.perf_counter() - t0) / reps
-        t = torch.tensor([hd], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        hd = float(t.item())
+        t = rank_max(torch, dist, hd)
+        hd = t
         k_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
         ctx.set_timing(False)
         alg_bytes = float(nq_total) * nt * 32
@@ -665,6 +674,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(frames, K, cfg)
+    if rehearsal:
+        line["rehearsal"] = ("ranks share %d GPU(s), gloo process group: a run of the multi-rank code path, not a "
+                             "scaling measurement" % torch.cuda.device_count())
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -26,7 +26,10 @@ def gather_rows(local, n_total, dst=0):
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [block_range(n_total, r, world) for r in range(world)]
     pad = max(e - b for b, e in sizes)
-    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # gloo gathers host tensors only: device rows are staged through the host there (RCCL
+    # gathers them where they are)
+    device = torch.device("cpu") if dist.get_backend() == "gloo" else local.device
+    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
     buf[: local.shape[0]] = local
     out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
