@@ -38,7 +38,7 @@ WORKLOADS = {
 PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": (78.6, "TFLOP/s"),
         "valu_fp32": (157.3, "TFLOP/s")}
 KERNEL_OF_GROUP = {
-    "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel", "select": "select_a + harris + select_b kernels",
+    "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel (per launch group - level 0, levels 1-7 -: <0> on the sampled tiles, fast_raise_kernel, <1> on the other tiles, fast_check_kernel, <2> over the redo list)", "select": "select_a + harris + select_b kernels",
     "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_bcast_kernel",
     "ratio": "ratio_kernel", "ransac_solve": "solve_front_kernel + solve_roots_kernel + solve_models_kernel (+ second-chart pass)", "ransac_score": "score_kernel",
     "ransac_other": "normalize / init / update / finish kernels",
@@ -440,9 +440,16 @@ def main():
         "model x match Sampson test, decided in single precision with a rounding bound, in fp64 when close) for the "
         "scoring kernel; "
         "achieved = algorithmic work of an average launch / mean launch duration by HIP events on the kernel's "
-        "stream inside the timed steps; traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the "
+        "stream inside the timed steps (for the FAST stage a launch is one launch group of up to five kernels, "
+        "bracketed as one: rocprofv3's durations of fast_kernel<0>, <1>, <2>, fast_raise_kernel and "
+        "fast_check_kernel per step add up to launches_per_step x avg_launch_ms); traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/ when the "
         "configuration matches")
 
+    ft = ctx.fast_thresholds(0)   # of the last timed step's first image
+    line["scene"]["fast_thresholds_image0"] = None if ft is None else {
+        "per_level": ft[0].tolist(), "levels_run_again": int(ft[1].sum()),
+        "note": "FAST threshold the unsampled tiles of a level ran with (20 = plain): raised towards the score cut "
+                "of the selection, results unchanged"}
     line["pair_roofline"] = pair_roofline(H, W, work, P, dt / args.steps)
 
     if not args.no_extras:

@@ -290,6 +290,12 @@ int vo_debug_candidates(vo_ctx* ctx, int image, int level, int32_t* out, int cap
  * pre-test, out[2] = FAST-9 corners, out[3] = candidates left after non-max suppression
  * and the border filter. */
 int vo_debug_fast_stats(vo_ctx* ctx, int enable, uint64_t out[4]);
+/* What the FAST stage of the most recent detect call did on one image when it ran
+ * with raised thresholds (batched calls; see fast_raise_kernel): out[l] = the
+ * threshold the unsampled tiles of level l ran with (20 = not raised), out[8 + l]
+ * = 1 if that level's tiles had to run again with the plain threshold.  *raised_out
+ * = 0 (and out untouched) if the call ran every tile with the plain threshold. */
+int vo_debug_fast_thresholds(vo_ctx* ctx, int image, int32_t out[16], int* raised_out);
 
 /* The five-point minimal solver alone: `count` sets of 5 correspondences in
  * normalised image coordinates (x1, x2: count x 5 x 2 doubles).  Es receives

@@ -194,6 +194,99 @@ def test_pyramid_blur_fast_stages(ctx, oracle, name):
         assert got == exp, f"FAST candidates level {l}: {len(got)} vs {len(exp)}"
 
 
+def _strong_texture_on_sampled_tiles(seed, height=480, width=640):
+    """Weak corners (grey steps of 26) everywhere, strong ones (steps of 190) only inside the level-0
+    FAST tiles that are sampled at the plain threshold: the sample promises far more strong
+    candidates than the level holds, so the raised threshold is too high and the level's other
+    tiles have to run again."""
+    rng = np.random.default_rng(seed)
+
+    def blocks(lo, hi):
+        img = np.zeros((height, width), np.uint8)
+        y = 0
+        while y < height:
+            bh = int(rng.integers(2, 5))
+            x = 0
+            while x < width:
+                bw = int(rng.integers(2, 5))
+                img[y:y + bh, x:x + bw] = lo if rng.random() < 0.5 else hi
+                x += bw
+            y += bh
+        return img
+
+    img, strong = blocks(100, 126), blocks(30, 220)
+    for ty in range((height - 62 + 31) // 32):
+        for tx in range((width - 62 + 63) // 64):
+            if (tx + 3 * ty) % 8 == 0:
+                ys, xs = 31 + 32 * ty, 31 + 64 * tx
+                img[ys:ys + 32, xs:xs + 64] = strong[ys:ys + 32, xs:xs + 64]
+    return img
+
+
+@pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 300), ("checker", 2000), ("kitti", 4000),
+                                        ("odd", 500), ("narrow", 300), ("threshold", 800), ("sampled_strong", 2000),
+                                        ("sampled_strong", 500)])
+def test_orb_detect_with_raised_fast_thresholds(ctx, oracle, monkeypatch, name, nfeat):
+    """Batched calls run most FAST tiles with a per-(image, level) threshold raised towards the
+    score cut of the selection; forced here on single images.  The keypoints and descriptors must
+    not change, the candidate lists may only lose candidates, and both outcomes - threshold kept,
+    tiles run again - must occur."""
+    img = _strong_texture_on_sampled_tiles(21) if name == "sampled_strong" else IMAGES[name]()
+    monkeypatch.setenv("VO_FAST_RAISE", "1")
+    gk, gd = ctx.orb_detect(img, nfeat)
+    info = ctx.fast_thresholds(0)
+    assert info is not None
+    thr, redo = info
+    cands = [ctx.debug_candidates(0, l) for l in range(8)]
+    monkeypatch.setenv("VO_FAST_RAISE", "0")
+    pk, pd = ctx.orb_detect(img, nfeat)
+    assert ctx.fast_thresholds(0) is None
+    ok, od = oracle.orb_detect(img, nfeat)
+    assert len(ok) > 0
+    assert gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+    assert pk.tobytes() == ok.tobytes() and np.array_equal(pd, od)
+    assert np.all(thr % 2 == 0) and np.all(thr >= 20) and np.all(thr <= 240)
+    for l in range(8):
+        full = set(map(tuple, ctx.debug_candidates(0, l).tolist()))
+        got = set(map(tuple, cands[l].tolist()))
+        assert len(got) == len(cands[l]) and got <= full, f"level {l}"
+        if thr[l] == 20 or redo[l]:
+            assert got == full, f"level {l}: the list must be complete"
+        else:   # everything at or above the raised threshold, plus the sampled tiles' weaker candidates
+            assert {c for c in full if c[2] >= thr[l]} <= got, f"level {l}"
+    if name == "synth640":
+        assert thr[0] > 20 and not redo[0]
+    if name == "sampled_strong":
+        assert thr[0] > 20 and redo[0]
+
+
+def test_pipeline_with_and_without_raised_fast_thresholds(ctx, monkeypatch):
+    """The batched pipeline raises the thresholds by itself from a dozen images on; its records
+    must not depend on it."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for k in range(8):
+        frames.extend(synth.frame_pair(300 + k))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    K = synth.default_K(640, 480)
+    out = []
+    for flag in ("0", "1", None):
+        if flag is None:
+            monkeypatch.delenv("VO_FAST_RAISE")
+        else:
+            monkeypatch.setenv("VO_FAST_RAISE", flag)
+        res = torch.zeros(8 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 8, 480, 640, 640, 480 * 640, 2000, 0.75, K, 1.0, 0.999, 0, res.data_ptr())
+        ctx.sync()
+        out.append(res.cpu().numpy().tobytes())
+        if flag is None:
+            assert ctx.fast_thresholds(3) is not None   # 16 images x 379 tiles: raised by default
+    assert out[0] == out[1] == out[2]
+    rec = np.frombuffer(out[0], capi.PAIR_DTYPE)
+    assert np.all(rec["valid"] == 1) and np.all(rec["n_kp1"] == 2000)
+
+
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 1000), ("checker", 2000), ("checker", 100),
                                         ("kitti", 4000), ("odd", 500), ("synth640", 37), ("narrow", 300),
                                         ("low", 300), ("edge68", 500), ("threshold", 800)])

@@ -25,7 +25,7 @@ EXPORTS = [
     "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
     "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
     "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
-    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_ticket", "vo_pipeline_wait", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_five_point",
+    "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_ticket", "vo_pipeline_wait", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_fast_thresholds", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
@@ -89,6 +89,7 @@ def load():
     lib.vo_debug_level.argtypes = [vp, i, i, i, vp, sz, C.POINTER(i), C.POINTER(i)]
     lib.vo_debug_candidates.argtypes = [vp, i, i, vp, i, C.POINTER(i)]
     lib.vo_debug_fast_stats.argtypes = [vp, i, vp]
+    lib.vo_debug_fast_thresholds.argtypes = [vp, i, vp, C.POINTER(i)]
     lib.vo_debug_five_point.argtypes = [vp, vp, vp, i, vp, vp]
     _lib = lib
     return lib
@@ -180,6 +181,13 @@ class Context:
         self._check(self.lib.vo_debug_level(self.h, image, level, int(blurred), _p(out), out.size, C.byref(w),
                                             C.byref(h)), "vo_debug_level")
         return out[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    def fast_thresholds(self, image):
+        """None if the last detection ran every FAST tile with the plain threshold, else
+        (thresholds[8], redo[8]) of one image."""
+        out, raised = np.zeros(16, np.int32), C.c_int()
+        self._check(self.lib.vo_debug_fast_thresholds(self.h, image, _p(out), C.byref(raised)), "vo_debug_fast_thresholds")
+        return (out[:8].copy(), out[8:].copy()) if raised.value else None
 
     def fast_stats(self, enable):
         """enable=True: start counting; False: stop and return dict(pixels, pretest_pass, corners, candidates)."""

@@ -28,6 +28,8 @@ struct LevelGeom {
     int kp_off;          // offset (entries) of the level's selected-keypoint list
     int kp_cap;
     int fast_tx, fast_ty, fast_tile0;   // FAST tile grid of the level and first flat tile id
+    int fast_ns;         // tiles of the level that are sampled at the plain threshold (all of them on a small level)
+    int fast_u0;         // position in the FAST tile table of the level's first unsampled tile (they are contiguous)
     int blur_tx, blur_ty, blur_tile0;
     uint32_t xtab, ytab; // offsets into the resize coefficient table (levels >= 1)
     uint32_t gtab;       // offset of the per-column-group table (12 dwords per four output columns)
@@ -43,6 +45,9 @@ struct Geom {
     int cand_stride;      // candidate entries per image
     int kp_stride;        // selected-keypoint entries per image
     int fast_tiles, blur_tiles;
+    // The FAST tile table lists level 0 first, then the other levels; inside each of the two
+    // groups the sampled tiles come first: fast_s0 of level 0's, fast_s1 of the other levels'.
+    int fast_s0, fast_s1;
     // per-tile (level << 24 | tile row << 12 | tile column) tables inside the resize table buffer,
     // and floor(2^32 / tiles) for the workgroup -> (image, tile) split
     uint32_t fast_ttab, blur_ttab, fast_magic, blur_magic;
@@ -97,6 +102,8 @@ struct vo_ctx {
     // word per image of the most recent detection call.
     vo::DevBuf flags, img_status;
     vo::DevBuf fast_stats;                // four 64-bit scene counters (vo_debug_fast_stats)
+    vo::DevBuf fast_thr, fast_redo;       // raised FAST threshold per (image, level); the two launch groups' redo lists
+    bool fast_raised = false;             // the most recent detection call ran with raised thresholds
     bool fast_stats_on = false;
     uint32_t* img_status_cur = nullptr;   // the half of img_status the most recent detection call uses
     int status_phase = 0;

@@ -5,6 +5,7 @@
 // stages keep OpenCV's operation order (built with -ffp-contract=off).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 #include "vo_internal.h"
@@ -181,6 +182,7 @@ constexpr int FP_N = FP_H * FP_W;            // bytes of the pixel tile
 // pixels next to them do not meet on one bank.
 constexpr int FI_OFF = FP_N + 64;
 constexpr int FQ1_N = 2 * FQ_N;              // a position can enter the first queue once per polarity
+enum { FAST_PLAIN = 0, FAST_RAISED = 1, FAST_REDO = 2 };   // fast_kernel's mode
 
 // Largest minimum over the sixteen 9-arcs of the ring (Bresenham circle of radius 3) around
 // p, minus the centre: > thr iff the pixel is a FAST-9/16 corner whose ring is brighter, and
@@ -258,11 +260,19 @@ __device__ __forceinline__ void wave_push(bool pass, uint16_t val, uint16_t* q, 
 //      the rare case that both did): it decides the corner test and is the corner score, so
 //      the ring is read once; scores go to an LDS score tile, corners to a second queue;
 // then 3x3 non-max suppression, the border filter and one global atomic per tile.
+//
+// MODE (see orb_run and fast_raise_kernel): FAST_PLAIN - threshold kFastThr, every candidate
+// reported; FAST_RAISED - the raised threshold of the tile's (image, level); FAST_REDO - a fixed
+// grid that walks the unsampled tiles of the (image, level)s on the redo list (none, as a rule),
+// threshold kFastThr again, reporting the candidates the raised pass left out.
+template <int MODE>
 __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __restrict__ in,
                                                    const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ tab,
                                                    uint32_t tile_first, uint32_t ntiles, uint32_t tile_magic,
                                                    uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-                                                   unsigned long long* __restrict__ stats) {
+                                                   unsigned long long* __restrict__ stats,
+                                                   const uint32_t* __restrict__ thr_tab,
+                                                   const uint32_t* __restrict__ redo_list, uint32_t redo_span) {
     __shared__ __attribute__((aligned(16))) uint8_t px[FI_OFF + FP_N];   // the tile, then 255 - tile at FI_OFF
     __shared__ __attribute__((aligned(16))) uint8_t sc[FS_H * FS_W];
     __shared__ __attribute__((aligned(16))) uint16_t q1[FQ1_N];
@@ -272,15 +282,35 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     __shared__ uint32_t n1, n2, nlist, gbase;
     __shared__ uint32_t colmask[32];
 
-    uint32_t work;
-    if (!xcd_remap(ntiles * (uint32_t)g.n_images, &work)) return;
-    int img, tile;
-    split_work(work, ntiles, tile_magic, &img, &tile);
-    tile += (int)tile_first;   // this launch covers tiles [tile_first, tile_first + ntiles) of every image
     const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t item = blockIdx.x;   // (FAST_REDO: position in the redo list x tiles of a level)
+    for (;;) {
+    int img, tile;
+    if constexpr (MODE == FAST_REDO) {
+        // redo_list[0] = entries, redo_list[1 + f] = image * kLevels + level; entry f owns the items
+        // [f * redo_span, (f + 1) * redo_span), of which the first (unsampled tiles of its level) are tiles
+        const uint32_t n_items = min(redo_list[0], (uint32_t)(g.n_images * kLevels)) * redo_span;
+        if (item >= n_items) return;
+        const uint32_t f = item / redo_span, k = item - f * redo_span;
+        item += gridDim.x;
+        const uint32_t e = redo_list[1 + f];
+        const LevelGeom& Lr = g.L[e % kLevels];
+        if (k >= (uint32_t)(Lr.fast_tx * Lr.fast_ty - Lr.fast_ns)) continue;
+        img = (int)(e / kLevels);
+        tile = Lr.fast_u0 + (int)k;
+    } else {
+        uint32_t work;
+        if (!xcd_remap(ntiles * (uint32_t)g.n_images, &work)) return;
+        split_work(work, ntiles, tile_magic, &img, &tile);
+        tile += (int)tile_first;   // this launch covers tiles [tile_first, tile_first + ntiles) of every image
+    }
     const uint32_t te = tab[g.fast_ttab + tile];
     const int l = (int)(te >> 24);
     const LevelGeom& L = g.L[l];
+    // corner threshold of this tile and the scores it reports, workgroup-uniform
+    uint32_t thr = (uint32_t)kFastThr, report_below = 256u;
+    if constexpr (MODE == FAST_RAISED) thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_tab[img * kLevels + l]);
+    if constexpr (MODE == FAST_REDO) report_below = thr_tab[img * kLevels + l];
     int x0 = kEdge + (int)(te & 0xFFFu) * FT_W, y0 = kEdge + (int)((te >> 12) & 0xFFFu) * FT_H;
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
@@ -344,6 +374,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     // brighter ring, the inverted one (+ FI_OFF) for a darker ring.
     {
         static_assert(kFastThr % 2 == 0 && kFastThr < 254, "the two-step average tests a - b >= thr + 1 exactly for even thr");
+        // (a raised threshold is even and at most kFastThrMax by construction: fast_raise_kernel)
         constexpr int PD = FP_W / 4;   // dwords per LDS row
         const uint32_t* px32 = reinterpret_cast<const uint32_t*>(px);
         const uint32_t* ix32 = px32 + FI_OFF / 4;
@@ -353,8 +384,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         // i.e. C + 255 - b <= 254 - thr: x <= 127 - thr / 2, i.e. bit 7 of (x + 128 + thr / 2) >> 1
         // clear - which also lets b - C == thr through (odd sums round down); the ring stage
         // decides exactly, so the pre-test may pass a few pixels too many.
-        constexpr uint32_t KT = (uint32_t)(128 - kFastThr / 2) * 0x01010101u;
-        constexpr uint32_t KB = (uint32_t)(128 + kFastThr / 2) * 0x01010101u;
+        const uint32_t KT = (128u - (thr >> 1)) * 0x01010101u;
+        const uint32_t KB = (128u + (thr >> 1)) * 0x01010101u;
         auto avg = [](uint32_t a, uint32_t b) -> uint32_t { return __builtin_amdgcn_lerp(a, b, 0u); };
         // A lane takes the dword at tile offset 3 * PD + i: consecutive lanes read consecutive
         // dwords whatever the row, so no read of this stage meets a bank conflict (the three
@@ -432,7 +463,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             const uint32_t e = q1[i];
             const int best = ring_arc_contrast(&px[e]);
             pos = e >= (uint32_t)FP_N ? e - (uint32_t)FI_OFF : e;
-            pass = best > kFastThr;
+            pass = best > (int)thr;
             if (pass) sc[pos - sc_shift] = (uint8_t)(best - 1);
         }
         wave_push(pass, (uint16_t)pos, q2, &n2, lane);
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         const int v = s[0], n0 = s[-1], n1 = s[1], n2 = s[-FS_W - 1], n3 = s[-FS_W], n4 = s[-FS_W + 1], n5 = s[FS_W - 1],
                   n6 = s[FS_W], n7 = s[FS_W + 1];
         const bool keep = v > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-        if (keep) {
+        if (keep && (uint32_t)v < report_below) {
             uint32_t slot = atomicAdd(&nlist, 1u);
             list[slot] = ((uint32_t)v << 24) | ((uint32_t)Y << 12) | (uint32_t)X;
         }
@@ -468,14 +499,92 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         atomicAdd(&stats[2], (unsigned long long)c2);
         atomicAdd(&stats[3], (unsigned long long)n);
     }
-    if (n == 0) return;
-    if (tid == 0) gbase = atomicAdd(&cand_cnt[img * kLevels + l], n);
-    __syncthreads();
-    uint32_t* out = cand + (size_t)img * g.cand_stride + L.cand_off;
-    for (uint32_t i = tid; i < n; i += 256) {
-        uint32_t pos = gbase + i;
-        if (pos < (uint32_t)L.cand_cap) out[pos] = list[i];
+    if (n != 0) {   // (workgroup-uniform)
+        if (tid == 0) gbase = atomicAdd(&cand_cnt[img * kLevels + l], n);
+        __syncthreads();
+        uint32_t* out = cand + (size_t)img * g.cand_stride + L.cand_off;
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint32_t pos = gbase + i;
+            if (pos < (uint32_t)L.cand_cap) out[pos] = list[i];
+        }
     }
+    if constexpr (MODE != FAST_REDO) return;
+    __syncthreads();   // the next tile reuses the queues and counters
+    }
+}
+
+// Raised FAST threshold of an (image, level) from the candidates of its sampled tiles.
+//
+// Only the candidates among the 2 * quota best scores of a level (and their ties) survive the
+// first cut of the selection, and a candidate's score - the largest threshold at which it is
+// still a corner - and its fate in the non-maximum suppression do not depend on corners that
+// score less than it does.  FAST with a threshold t' >= kFastThr therefore reports exactly the
+// candidates of the plain run that score >= t', and as soon as there are 2 * quota of those the
+// selection sees the same survivors.  On a densely textured level most of the plain run's work -
+// ring tests and scores of tens of thousands of corners - goes into candidates far below the
+// cut, so: the sampled tiles (every eighth, spread over the level) run first with the plain
+// threshold; this kernel takes the largest even t' at which their candidates, scaled to the
+// whole level, still promise 1.5 times the 2 * quota needed; the other tiles run with t';
+// fast_check_kernel counts what came of it, and where the promise did not hold the tiles run
+// again with the plain threshold and add what was left out, so the list is complete either way.
+// A workgroup per (image, level).
+constexpr int kFastThrMax = 240;
+constexpr int kRaiseMarginNum = 3, kRaiseMarginDen = 2;
+__global__ __launch_bounds__(256) void fast_raise_kernel(Geom g, int l_first, const uint32_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cand_cnt,
+                                                         uint32_t* __restrict__ thr_tab) {
+    __shared__ uint32_t ge[256];
+    __shared__ uint32_t best;
+    const int img = blockIdx.x, l = l_first + blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g.L[l];
+    const int nt = L.fast_tx * L.fast_ty, ns = L.fast_ns;
+    if (ns >= nt || L.quota == 0) {   // (no tile left to run with a raised threshold)
+        if (tid == 0) thr_tab[img * kLevels + l] = (uint32_t)kFastThr;
+        return;
+    }
+    ge[tid] = 0;
+    if (tid == 0) best = (uint32_t)kFastThr;
+    __syncthreads();
+    const uint32_t total = min(cand_cnt[img * kLevels + l], (uint32_t)L.cand_cap);
+    const uint32_t* cl = cand + (size_t)img * g.cand_stride + L.cand_off;
+    for (uint32_t i = tid; i < total; i += 256) atomicAdd(&ge[cl[i] >> 24], 1u);
+    __syncthreads();
+    // suffix sums: ge[s] = candidates of the sampled tiles with a score >= s
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = tid + o < 256 ? ge[tid + o] : 0u;
+        __syncthreads();
+        ge[tid] += v;
+        __syncthreads();
+    }
+    // ge[t] * nt / ns >= kRaiseMargin (as a ratio of two integers) * 2 * quota
+    const unsigned long long have = (unsigned long long)kRaiseMarginDen * ge[tid] * (unsigned long long)nt;
+    const unsigned long long want = (unsigned long long)kRaiseMarginNum * (unsigned long long)(2 * L.quota) * (unsigned long long)ns;
+    if ((tid & 1) == 0 && tid > kFastThr && tid <= kFastThrMax && have >= want) atomicMax(&best, (uint32_t)tid);
+    __syncthreads();
+    if (tid == 0) thr_tab[img * kLevels + l] = best;
+}
+
+// After the raised pass: does the (image, level) hold the 2 * quota candidates scoring at least
+// its raised threshold that make its list complete for the selection?  If not, it joins the
+// redo list (redo_list[0] = entries, then image * kLevels + level each) that the redo pass walks.
+__global__ __launch_bounds__(256) void fast_check_kernel(Geom g, int l_first, const uint32_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cand_cnt,
+                                                         const uint32_t* __restrict__ thr_tab,
+                                                         uint32_t* __restrict__ redo_list) {
+    __shared__ uint32_t n_ge;
+    const int img = blockIdx.x, l = l_first + blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g.L[l];
+    const uint32_t raised = thr_tab[img * kLevels + l];
+    if (raised <= (uint32_t)kFastThr) return;   // (the other tiles ran with the plain threshold)
+    if (tid == 0) n_ge = 0;
+    __syncthreads();
+    const uint32_t total = min(cand_cnt[img * kLevels + l], (uint32_t)L.cand_cap);
+    const uint32_t* cl = cand + (size_t)img * g.cand_stride + L.cand_off;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < total; i += 256) mine += (cl[i] >> 24) >= raised ? 1u : 0u;
+    if (mine) atomicAdd(&n_ge, mine);
+    __syncthreads();
+    if (tid == 0 && n_ge < (uint32_t)(2 * L.quota)) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)(img * kLevels + l);
 }
 
 // ------------------------------------------------------------------ select
@@ -1418,10 +1527,30 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
                 }
             }
         }
+        // FAST tiles: level 0, then the other levels (two launch groups); inside a group the sampled
+        // tiles first (fast_raise_kernel: every eighth tile of a level, on a diagonal pattern so
+        // that they spread over rows and columns; a level of fewer than 24 tiles is sampled whole)
         n.fast_ttab = (uint32_t)tab.size();
-        for (int l = 0; l < kLevels; ++l)
+        auto sampled = [&](int l, int tx, int ty) {
+            return n.L[l].fast_tx * n.L[l].fast_ty < 24 || (tx + 3 * ty) % 8 == 0;
+        };
+        for (int l = 0; l < kLevels; ++l) {
+            n.L[l].fast_ns = 0;
             for (int ty = 0; ty < n.L[l].fast_ty; ++ty)
-                for (int tx = 0; tx < n.L[l].fast_tx; ++tx) tab.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | (uint32_t)tx);
+                for (int tx = 0; tx < n.L[l].fast_tx; ++tx) n.L[l].fast_ns += sampled(l, tx, ty) ? 1 : 0;
+        }
+        n.fast_s0 = n.L[0].fast_ns;
+        n.fast_s1 = 0;
+        for (int l = 1; l < kLevels; ++l) n.fast_s1 += n.L[l].fast_ns;
+        for (int group = 0; group < 2; ++group)
+            for (int pass = 0; pass < 2; ++pass)   // 0: the sampled tiles, 1: the others
+                for (int l = group ? 1 : 0; l < (group ? kLevels : 1); ++l) {
+                    if (pass == 1) n.L[l].fast_u0 = (int)(tab.size() - n.fast_ttab);
+                    for (int ty = 0; ty < n.L[l].fast_ty; ++ty)
+                        for (int tx = 0; tx < n.L[l].fast_tx; ++tx)
+                            if (sampled(l, tx, ty) == (pass == 0))
+                                tab.push_back(((uint32_t)l << 24) | ((uint32_t)ty << 12) | (uint32_t)tx);
+                }
         n.blur_ttab = (uint32_t)tab.size();
         for (int l = 0; l < kLevels; ++l)
             for (int ty = 0; ty < n.L[l].blur_ty; ++ty)
@@ -1471,6 +1600,8 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
     if ((rc = ensure(c, c->blur, N * g.blk_stride + 256))) return rc;
     if ((rc = ensure(c, c->cand, N * std::max(g.cand_stride, 1) * 4))) return rc;
     if ((rc = ensure(c, c->cand_cnt, N * kLevels * 4))) return rc;
+    if ((rc = ensure(c, c->fast_thr, N * kLevels * 4))) return rc;
+    if ((rc = ensure(c, c->fast_redo, 2 * (1 + N * kLevels) * 4))) return rc;   // a redo list per launch group
     if ((rc = ensure(c, c->kp_x, N * g.kp_stride * 2))) return rc;
     if ((rc = ensure(c, c->kp_y, N * g.kp_stride * 2))) return rc;
     if ((rc = ensure(c, c->kp_resp, N * g.kp_stride * 4))) return rc;
@@ -1505,11 +1636,48 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     // level 0 (needs only the input) and the other levels are separate FAST launches
     const uint32_t tiles0 = (uint32_t)(kLevels > 1 ? g.L[1].fast_tile0 : g.fast_tiles);
     const uint32_t tiles_up = (uint32_t)g.fast_tiles - tiles0;
-    auto launch_fast = [&](hipStream_t fs, uint32_t first, uint32_t count) {
+    unsigned long long* const stats = c->fast_stats_on ? (unsigned long long*)c->fast_stats.p : nullptr;
+    auto launch_fast_tiles = [&](hipStream_t fs, uint32_t first, uint32_t count, bool raised) {
         const uint32_t magic = (uint32_t)std::min<unsigned long long>(0x100000000ull / count, 0xFFFFFFFFull);
-        hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(count * (uint32_t)N)), dim3(256), 0, fs, g, d_imgs, pyr,
-                           (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p, (uint32_t*)c->cand_cnt.p,
-                           c->fast_stats_on ? (unsigned long long*)c->fast_stats.p : nullptr);
+        if (raised)
+            hipLaunchKernelGGL(fast_kernel<FAST_RAISED>, dim3(xcd_grid(count * (uint32_t)N)), dim3(256), 0, fs, g, d_imgs, pyr,
+                               (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p,
+                               (uint32_t*)c->cand_cnt.p, stats, (const uint32_t*)c->fast_thr.p, nullptr, 0u);
+        else
+            hipLaunchKernelGGL(fast_kernel<FAST_PLAIN>, dim3(xcd_grid(count * (uint32_t)N)), dim3(256), 0, fs, g, d_imgs, pyr,
+                               (const uint32_t*)c->tab.p, first, count, magic, (uint32_t*)c->cand.p,
+                               (uint32_t*)c->cand_cnt.p, stats, nullptr, nullptr, 0u);
+    };
+    // Raised thresholds (fast_raise_kernel) pay on batches: the group becomes five launches, three
+    // of them FAST passes, which a call on a few images only feels as launch latency.  The scene
+    // counters describe the plain run, so they switch it off as well.  VO_FAST_RAISE=0 / 1
+    // switches it off / on whatever the batch (measurement and test aid).
+    bool raise = (size_t)N * (size_t)g.fast_tiles >= 4096 && !c->fast_stats_on;
+    if (const char* e = getenv("VO_FAST_RAISE")) raise = e[0] == '1' && !c->fast_stats_on;
+    c->fast_raised = raise;
+    if (raise) VO_HIP(c, hipMemsetAsync(c->fast_redo.p, 0, c->fast_redo.bytes, s));   // (before the fork below)
+    // one launch group: tiles [first, first + count) of the table, the first `ns` of them sampled,
+    // levels [l_first, l_first + n_lev)
+    auto launch_fast = [&](hipStream_t fs, uint32_t first, uint32_t count, uint32_t ns, int l_first, int n_lev) {
+        if (!raise || ns >= count) {
+            launch_fast_tiles(fs, first, count, false);
+            return;
+        }
+        uint32_t* const redo_list = (uint32_t*)c->fast_redo.p + (l_first ? 1 + (size_t)N * kLevels : 0);
+        uint32_t span = 0;   // unsampled tiles of the group's largest level
+        for (int l = l_first; l < l_first + n_lev; ++l)
+            span = std::max(span, (uint32_t)(g.L[l].fast_tx * g.L[l].fast_ty - g.L[l].fast_ns));
+        if (ns > 0) launch_fast_tiles(fs, first, ns, false);
+        hipLaunchKernelGGL(fast_raise_kernel, dim3(N, n_lev), dim3(256), 0, fs, g, l_first, (const uint32_t*)c->cand.p,
+                           (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->fast_thr.p);
+        launch_fast_tiles(fs, first + ns, count - ns, true);
+        hipLaunchKernelGGL(fast_check_kernel, dim3(N, n_lev), dim3(256), 0, fs, g, l_first, (const uint32_t*)c->cand.p,
+                           (const uint32_t*)c->cand_cnt.p, (const uint32_t*)c->fast_thr.p, redo_list);
+        // (a grid that fills the GPU a few times over; it returns at once when the list is empty)
+        const uint32_t redo_grid = (uint32_t)std::min<unsigned long long>((unsigned long long)(count - ns) * N, 4096ull);
+        hipLaunchKernelGGL(fast_kernel<FAST_REDO>, dim3(redo_grid), dim3(256), 0, fs, g, d_imgs, pyr,
+                           (const uint32_t*)c->tab.p, 0u, 0u, 0u, (uint32_t*)c->cand.p, (uint32_t*)c->cand_cnt.p, stats,
+                           (const uint32_t*)c->fast_thr.p, (const uint32_t*)redo_list, span);
     };
     // The resize chain is seven dependent, bandwidth- and latency-bound launches that leave the
     // vector ALUs mostly idle, FAST is bound by them: level 0's FAST runs beside the chain on the
@@ -1520,7 +1688,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
         VO_HIP(c, hipEventRecord(c->ev_fork, s));
         VO_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         t_begin_on(c, VO_T_FAST, c->aux);
-        launch_fast(c->aux, 0, tiles0);
+        launch_fast(c->aux, 0, tiles0, (uint32_t)g.fast_s0, 0, 1);
         t_end_on(c, VO_T_FAST, c->aux);
         VO_HIP(c, hipEventRecord(c->ev_fast0, c->aux));
     }
@@ -1534,7 +1702,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     t_end(c, VO_T_RESIZE);
     if (tiles0 > 0 && !fast0_aside) {
         t_begin(c, VO_T_FAST);
-        launch_fast(s, 0, tiles0);
+        launch_fast(s, 0, tiles0, (uint32_t)g.fast_s0, 0, 1);
         t_end(c, VO_T_FAST);
     }
     // The upper levels' launch waits for level 0's: two FAST launches side by side only halve each
@@ -1543,7 +1711,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     if (fast0_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_fast0, 0));
     if (tiles_up > 0) {
         t_begin(c, VO_T_FAST);
-        launch_fast(s, tiles0, tiles_up);
+        launch_fast(s, tiles0, tiles_up, (uint32_t)g.fast_s1, 1, kLevels - 1);
         t_end(c, VO_T_FAST);
     }
     // The blur needs only the pyramid, candidate selection and orientation are mostly latency
@@ -1704,6 +1872,32 @@ extern "C" int vo_debug_fast_stats(vo_ctx* c, int enable, uint64_t out[4]) {
     for (int k = 0; k < 4; ++k) out[k] = 0;
     if (c->fast_stats_on) VO_HIP(c, hipMemcpy(out, c->fast_stats.p, 32, hipMemcpyDeviceToHost));
     c->fast_stats_on = false;
+    return VO_OK;
+}
+
+extern "C" int vo_debug_fast_thresholds(vo_ctx* c, int image, int32_t out[16], int* raised_out) {
+    if (!c || !c->geom_valid || image < 0 || image >= c->g.n_images || !out || !raised_out)
+        return c ? fail(c, VO_ERR_INVALID, "vo_debug_fast_thresholds: bad argument") : VO_ERR_INVALID;
+    *raised_out = c->fast_raised ? 1 : 0;
+    if (!c->fast_raised) return VO_OK;
+    VO_HIP(c, hipSetDevice(c->device));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t t[kLevels];
+    VO_HIP(c, hipMemcpy(t, (const uint32_t*)c->fast_thr.p + image * kLevels, kLevels * 4, hipMemcpyDeviceToHost));
+    const size_t per_group = 1 + (size_t)c->g.n_images * kLevels;
+    std::vector<uint32_t> lists(2 * per_group);
+    VO_HIP(c, hipMemcpy(lists.data(), c->fast_redo.p, lists.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < kLevels; ++l) {
+        // a level sampled whole is never touched by the raised or the redo pass
+        const bool whole = c->g.L[l].fast_ns >= c->g.L[l].fast_tx * c->g.L[l].fast_ty;
+        out[l] = whole ? kFastThr : (int32_t)t[l];
+        out[kLevels + l] = 0;
+    }
+    for (int group = 0; group < 2; ++group) {
+        const uint32_t* list = lists.data() + group * per_group;
+        for (uint32_t f = 0; f < std::min<uint32_t>(list[0], (uint32_t)per_group - 1); ++f)
+            if ((int)(list[1 + f] / kLevels) == image) out[kLevels + list[1 + f] % kLevels] = 1;
+    }
     return VO_OK;
 }
 
