@@ -6,7 +6,9 @@
 Reads the newest rocprofv3 counter_collection.csv of each pass directory (tools/pmc_sq.sh
 writes them; its bench.py command launches full batches only) and averages every counter and
 the dispatch duration over all dispatches of a kernel - an average launch, as in bench.py's
-roofline (FAST has two launches per step, level 0 and the upper levels; resize seven).  `valu_issue_frac` is the share of the GPU's vector-ALU
+roofline (resize has seven launches per step; the FAST stage two launch groups, level 0 and the
+upper levels, each of fast_kernel<0> on the sampled tiles, <1> on the others with the raised
+threshold and <2> over the - normally empty - redo list: the three are listed separately).  `valu_issue_frac` is the share of the GPU's vector-ALU
 issue slots the kernel's wavefront instructions fill while it runs: one wave64 VALU instruction
 occupies a SIMD for four cycles, 256 CUs x 4 SIMDs, clock from the agent's max (2400 MHz).
 """
@@ -27,14 +29,16 @@ for d in sys.argv[1:3]:
     if not files:
         continue
     for r in csv.DictReader(open(files[-1])):
-        name = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1].split(" ")[-1]
+        name = r["Kernel_Name"].split("(")[0].split("::")[-1].split(" ")[-1]
+        if not name.startswith("fast_kernel"):   # (fast_kernel<0> / <1> / <2> do different work: kept apart)
+            name = name.split("<")[0]
         key = (d, r["Dispatch_Id"])
         per[name][key][r["Counter_Name"]] = float(r["Counter_Value"])
         meta[key] = (int(r["Grid_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 out = {}
 for name, disp in per.items():
-    if not name.endswith("_kernel"):
+    if not name.split("<")[0].endswith("_kernel"):
         continue
     keys = list(disp)
     acc = collections.defaultdict(list)

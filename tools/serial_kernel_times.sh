@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=$PWD
 rm -rf $R/gpurun_out/prof_serial
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-hamming --no-sequence --no-aux-scene --no-dropin --warmup 1 --steps 2 "$@" > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-hamming --no-sequence --no-aux-scene --no-dropin --no-scene-counters --warmup 1 --steps 2 "$@" > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
 python3 - $(ls $R/gpurun_out/prof_serial/*/*kernel_trace.csv | head -1) <<'PY'
 import csv, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
@@ -15,10 +15,10 @@ for r in rows:
 tot = 0.0
 out = []
 for k, v in per.items():
-    if len(v) % 10:
+    if len(v) % 9:
         continue
-    n = len(v) // 10                     # launches per pipeline call: 1 warm-up, 1 scene-counter call, then the
-    ser = v[2 * n:5 * n]                 # serial pass (calls 2..4), 3 calls of the RANSAC split, 2 timed steps
+    n = len(v) // 9                      # launches per pipeline call: 1 warm-up, then the serial pass
+    ser = v[n:4 * n]                     # (calls 1..3), 3 calls of the RANSAC split, 2 timed steps
     out.append((sum(ser) / 3e3, n, k))
     tot += sum(ser) / 3e3
 for us, n, k in sorted(out, reverse=True):
