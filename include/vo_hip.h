@@ -198,11 +198,14 @@ int vo_find_essential(vo_ctx* ctx, const float* p1, const float* p2, int n, cons
  * as the reference's main loop runs them (ref:src/main.cpp:162-170), with every
  * intermediate kept in HBM.  Pair p uses images 2p and 2p+1 of d_imgs.
  * d_results: n_pairs records in device memory.  The call only enqueues:
- * everything behind the kNN search (ratio test, RANSAC rounds, pose recovery)
- * runs on a second stream of the context so that the next call's detection
- * overlaps it, and d_results is complete after vo_sync() (which
+ * everything behind the kNN search (ratio test, RANSAC rounds, pose recovery:
+ * the call's tail) runs on one of two further streams of the context, which
+ * consecutive calls use alternately, so that the next call's detection and the
+ * next call's tail overlap it; d_results is complete after vo_sync() (which
  * waits for every stream of the context; waiting on vo_ctx_stream() alone is
- * not enough). */
+ * not enough).  Consecutive calls that write overlapping records are ordered
+ * (the later call's records are what is left); give consecutive calls distinct
+ * record buffers to let their tails run side by side. */
 int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int rows, int cols, int step,
                           size_t image_stride, int max_features, float ratio, const double K[4],
                           double threshold, double confidence, int fixed_iters,
@@ -217,8 +220,10 @@ int vo_pipeline_pairs_dev(vo_ctx* ctx, const uint8_t* d_imgs, int n_pairs, int r
  * e.g. by the upload of the batch after next) or has written all its result
  * records (VO_WAIT_RESULTS) - without waiting for calls enqueued after it, so the
  * RANSAC rounds of one batch keep running beside the detection of the next.
- * Calls finish in order; the last VO_TICKET_RING tickets are tracked one by one,
- * an older one is waited for through a younger call.  Unlike vo_sync() this does
+ * Every other call shares a tail stream and those finish in order; the last
+ * VO_TICKET_RING tickets are tracked one by one, an older one is waited for
+ * through the younger call that took its slot (VO_TICKET_RING is even, so that
+ * call ran on the same tail stream).  Unlike vo_sync() this does
  * not report truncated keypoint lists; vo_pair_result.status carries them. */
 enum { VO_WAIT_INPUTS = 1, VO_WAIT_RESULTS = 2, VO_TICKET_RING = 4 };
 unsigned long long vo_pipeline_ticket(vo_ctx* ctx);

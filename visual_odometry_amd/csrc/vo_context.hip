@@ -17,6 +17,7 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p) {
         VO_HIP(c, hipStreamSynchronize(c->stream));
         if (c->side) VO_HIP(c, hipStreamSynchronize(c->side));
+        if (c->alt.side) VO_HIP(c, hipStreamSynchronize(c->alt.side));
         if (c->aux) VO_HIP(c, hipStreamSynchronize(c->aux));
         VO_HIP(c, hipFree(b.p));
         b.p = nullptr;
@@ -58,17 +59,27 @@ void t_end_on(vo_ctx* c, int group, hipStream_t s) {
 
 void t_end(vo_ctx* c, int group) { t_end_on(c, group, c->stream); }
 
-int join_side(vo_ctx* c) {
-    if (!c->side_busy) return VO_OK;
-    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_rdone, 0));
-    c->side_busy = false;
+int join_side(vo_ctx* c) {   // (both tail sets: either may still run a batch's tail)
+    if (c->side_busy) {
+        VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_rdone, 0));
+        c->side_busy = false;
+    }
+    if (c->alt.side_busy) {
+        VO_HIP(c, hipStreamWaitEvent(c->stream, c->alt.ev_rdone, 0));
+        c->alt.side_busy = false;
+    }
     return VO_OK;
 }
 
 int join_tail(vo_ctx* c) {
-    if (!c->tail_pending) return VO_OK;
-    VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));
-    c->tail_pending = false;
+    if (c->tail_pending) {
+        VO_HIP(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+        c->tail_pending = false;
+    }
+    if (c->alt.tail_pending) {
+        VO_HIP(c, hipStreamWaitEvent(c->stream, c->alt.ev_tail, 0));
+        c->alt.tail_pending = false;
+    }
     return VO_OK;
 }
 
@@ -115,6 +126,10 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
         hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rdone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->alt.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->alt.ev_init, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->alt.ev_rdone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->alt.ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess ||
@@ -135,8 +150,13 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->alt.side) (void)hipStreamSynchronize(c->alt.side);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
-    DevBuf* bufs[] = {&c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
+#define X(name) if (c->alt.name.p) (void)hipFree(c->alt.name.p);
+    VO_TAIL_BUFS(X)
+#undef X
+    DevBuf* bufs[] = {&c->fast_thr, &c->fast_redo,
+                      &c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
                       &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->img_status, &c->fast_stats, &c->st_img,   &c->st_kps,   &c->st_desc,
                       &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->st_down,  &c->m_top2,   &c->m_qidx,
                       &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
@@ -150,6 +170,9 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     if (c->ev_rdone) (void)hipEventDestroy(c->ev_rdone);
     if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+    if (c->alt.ev_init) (void)hipEventDestroy(c->alt.ev_init);
+    if (c->alt.ev_rdone) (void)hipEventDestroy(c->alt.ev_rdone);
+    if (c->alt.ev_tail) (void)hipEventDestroy(c->alt.ev_tail);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
     if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
@@ -158,6 +181,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
         if (c->ev_out[k]) (void)hipEventDestroy(c->ev_out[k]);
     }
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->alt.side) (void)hipStreamDestroy(c->alt.side);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -171,9 +195,10 @@ extern "C" int vo_sync(vo_ctx* c) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
     VO_HIP(c, hipStreamSynchronize(c->side));
+    VO_HIP(c, hipStreamSynchronize(c->alt.side));
     VO_HIP(c, hipStreamSynchronize(c->aux));
-    c->side_busy = false;
-    c->tail_pending = false;
+    c->side_busy = c->alt.side_busy = false;
+    c->tail_pending = c->alt.tail_pending = false;
     return take_truncation(c, "vo_sync");
 }
 
@@ -181,6 +206,7 @@ extern "C" int vo_set_timing(vo_ctx* c, int groups) {
     if (!c) return VO_ERR_INVALID;
     VO_HIP(c, hipStreamSynchronize(c->stream));
     VO_HIP(c, hipStreamSynchronize(c->side));
+    VO_HIP(c, hipStreamSynchronize(c->alt.side));
     VO_HIP(c, hipStreamSynchronize(c->aux));
     c->timing = (unsigned)groups & ((1u << VO_T_COUNT) - 1u);
     for (auto& v : c->ev_pairs) v.clear();
@@ -192,7 +218,7 @@ extern "C" float vo_kernel_time_ms(vo_ctx* c, int group, int* launches) {
     if (launches) *launches = 0;
     if (!c || group < 0 || group >= VO_T_COUNT) return -1.f;
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->side) != hipSuccess ||
-        hipStreamSynchronize(c->aux) != hipSuccess)
+        hipStreamSynchronize(c->alt.side) != hipSuccess || hipStreamSynchronize(c->aux) != hipSuccess)
         return -1.f;
     double sum = 0;
     int n = 0;

@@ -62,6 +62,27 @@ struct DevBuf {
 
 }  // namespace vo
 
+// What one batch's tail (ratio test, counts, RANSAC rounds, pose recovery) owns: its stream, the
+// events that order it against the main stream, the kNN table and match lists it reads and the
+// RANSAC workspace.  A context has two such sets and consecutive pipeline calls alternate between
+// them (vo_ctx::swap_tail), so that the tails of two batches - chains of small dependent launches
+// that leave most of the GPU idle - run side by side.  The fields live directly in vo_ctx (the
+// set in use) and in vo_ctx::alt (the other one).
+#define VO_TAIL_BUFS(X)                                                                                        \
+    X(st_idx) X(st_dist) X(m_top2) X(m_qidx) X(m_tidx) X(m_dist) X(m_p1) X(m_p2) X(m_cnt) X(r_state) X(r_samples) \
+    X(r_models) X(r_nmodels) X(r_models2) X(r_nmodels2) X(r_retry) X(r_roots) X(r_nroots) X(r_counts) X(r_best)   \
+    X(r_mask) X(r_pts) X(r_ptsf)
+struct vo_tail_set {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_init = nullptr, ev_rdone = nullptr, ev_tail = nullptr;
+    bool side_busy = false, tail_pending = false;
+    const void* res_begin = nullptr;   // result records the set's most recent tail writes
+    const void* res_end = nullptr;
+#define X(name) vo::DevBuf name;
+    VO_TAIL_BUFS(X)
+#undef X
+};
+
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +105,22 @@ struct vo_ctx {
     // FAST on level 0 needs only the input images: it runs on a third stream beside the resize
     // chain that builds the other levels (ev_fork orders it after the counter reset, ev_fast0
     // orders candidate selection after it).
+    const void* res_begin = nullptr;   // result records the most recent tail on `side` writes
+    const void* res_end = nullptr;
+    vo_tail_set alt;                   // the other tail set (see vo_tail_set)
+    void swap_tail() {
+        std::swap(side, alt.side);
+        std::swap(ev_init, alt.ev_init);
+        std::swap(ev_rdone, alt.ev_rdone);
+        std::swap(ev_tail, alt.ev_tail);
+        std::swap(side_busy, alt.side_busy);
+        std::swap(tail_pending, alt.tail_pending);
+        std::swap(res_begin, alt.res_begin);
+        std::swap(res_end, alt.res_end);
+#define X(name) std::swap(name, alt.name);
+        VO_TAIL_BUFS(X)
+#undef X
+    }
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fast0 = nullptr, ev_blur = nullptr;
     std::string err;

@@ -34,6 +34,9 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
     VO_HIP(c, hipSetDevice(c->device));
     int rc;
+    // this call's tail takes the tail set the call before the previous one used: it runs beside
+    // the previous call's tail (and behind the older one, in stream order)
+    c->swap_tail();
     if ((rc = orb_prepare(c, n_images, rows, cols, step, image_stride, max_features))) return rc;
     const int cap = c->g.kp_stride;   // quota + slack of every level: the detector cannot return more
     if ((rc = ensure(c, c->p_kps, (size_t)n_images * cap * sizeof(vo_keypoint)))) return rc;
@@ -65,6 +68,14 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
     hipStream_t side = c->side;
     VO_HIP(c, hipEventRecord(c->ev_init, c->stream));
     VO_HIP(c, hipStreamWaitEvent(side, c->ev_init, 0));
+    // a caller that hands consecutive calls the same result records gets them written in call
+    // order: this tail then starts behind the previous call's, as it did with a single tail stream
+    const uint8_t* const rb = (const uint8_t*)d_results;
+    const uint8_t* const re = rb + (size_t)n_pairs * sizeof(vo_pair_result);
+    if (c->alt.side_busy && rb < (const uint8_t*)c->alt.res_end && (const uint8_t*)c->alt.res_begin < re)
+        VO_HIP(c, hipStreamWaitEvent(side, c->alt.ev_rdone, 0));
+    c->res_begin = rb;
+    c->res_end = re;
     if ((rc = ratio_launch(c, (const int32_t*)c->st_idx.p, (const int32_t*)c->st_dist.p, cnt, pair_step, cap, n_pairs,
                            ratio, kps, kps + cap, (size_t)pair_step * cap, (int32_t*)c->m_qidx.p, (int32_t*)c->m_tidx.p,
                            (float*)c->m_dist.p, (float*)c->m_p1.p, (float*)c->m_p2.p, (int32_t*)c->m_cnt.p, side)))
@@ -90,7 +101,9 @@ extern "C" int vo_pipeline_wait(vo_ctx* c, unsigned long long ticket, int what) 
     if (ticket == 0 || ticket > c->call_seq || (what & ~(VO_WAIT_INPUTS | VO_WAIT_RESULTS)) || what == 0)
         return fail(c, VO_ERR_INVALID, "vo_pipeline_wait: no such ticket or nothing to wait for");
     VO_HIP(c, hipSetDevice(c->device));
-    // a slot that a younger call has taken over marks a later point of the same streams
+    // a slot that a younger call has taken over marks a later point of the same streams (the
+    // calls alternate between two tail streams and the ring has an even number of slots)
+    static_assert(VO_TICKET_RING % 2 == 0, "a ticket's slot is reused by calls on the same tail stream");
     if (what & VO_WAIT_INPUTS) VO_HIP(c, hipEventSynchronize(c->ev_in[ticket % VO_TICKET_RING]));
     if (what & VO_WAIT_RESULTS) VO_HIP(c, hipEventSynchronize(c->ev_out[ticket % VO_TICKET_RING]));
     return VO_OK;
