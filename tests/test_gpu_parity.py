@@ -878,6 +878,52 @@ def test_pipeline_back_to_back_calls_are_independent(ctx):
 
 
 @pytest.mark.gpu
+def test_pipeline_calls_sharing_result_records_stay_ordered(ctx):
+    """Consecutive calls run their tails on alternate streams; when they are handed the same
+    result records the later call's records must be what is left - also when the earlier call
+    is the larger, slower one - while calls with records of their own each keep theirs."""
+    import torch
+    from visual_odometry_amd import capi
+
+    def batch(seeds, sparse):
+        frames = []
+        for s_ in seeds:
+            frames += list(synth.frame_pair(s_, sparse=True, moving_fraction=0.6, n_layers=24) if sparse
+                           else synth.frame_pair(s_))
+        return len(seeds), torch.from_numpy(np.stack(frames)).cuda()
+
+    def run(b, res):
+        ctx.pipeline_pairs_dev(b[1].data_ptr(), b[0], 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res.data_ptr())
+
+    def records(res, n):
+        return np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)[:n].copy()
+
+    big, small = batch(range(700, 706), True), batch(range(710, 712), False)   # many RANSAC rounds / few
+    alone = []
+    for b_ in (big, small):
+        res = torch.zeros(6 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        run(b_, res)
+        ctx.sync()
+        alone.append(records(res, b_[0]))
+    assert alone[0]["ransac_iters"].mean() > 3 * alone[1]["ransac_iters"].mean()
+    shared = torch.zeros(6 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    own = torch.zeros(6 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        shared.zero_()
+        own.zero_()
+        torch.cuda.synchronize()
+        run(big, shared)
+        run(small, shared)      # same records: ordered behind the first call's tail
+        run(big, own)           # records of its own: free to run beside the second call's tail
+        ctx.sync()
+        got = records(shared, 6)
+        assert got[:2].tobytes() == alone[1].tobytes()
+        assert got[2:].tobytes() == alone[0][2:].tobytes()
+        assert records(own, 6).tobytes() == alone[0].tobytes()
+
+
+@pytest.mark.gpu
 def test_pipeline_tickets_release_inputs_and_results_per_call(ctx):
     """vo_pipeline_wait: after VO_WAIT_INPUTS for a call its image buffer may be overwritten while
     the call's RANSAC rounds (and a younger call) are still running; after VO_WAIT_RESULTS its
