@@ -428,7 +428,7 @@ def main():
                    if cfg["sequence"] else "independent pairs, both images of every pair detected",
                    "image": f"{W}x{H}", "max_features": nfeat, "ratio": 0.75,
                    "ransac": "adaptive<=1000" if fixed == 0 else f"fixed {fixed}", "parallelism": f"pairs x{world}",
-                   "streams_per_gpu": n_streams},
+                   "streams_per_gpu": n_streams, "record_buffers_per_context": 2},
         "roofline": roofline_of(dominant, work, dom_avg_ms, dom_launches, args.steps, args.workload, P),
         "scene": scene_stats(stats, out),
         "pipeline": {"kernel_group_ms_per_step_single_stream": kernel_ms,
