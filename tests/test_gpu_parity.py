@@ -217,7 +217,7 @@ def _strong_texture_on_sampled_tiles(seed, height=480, width=640):
     img, strong = blocks(100, 126), blocks(30, 220)
     for ty in range((height - 62 + 31) // 32):
         for tx in range((width - 62 + 63) // 64):
-            if (tx + 3 * ty) % 8 == 0:
+            if ((tx >> 1) + 3 * ty) % 8 == 0:
                 ys, xs = 31 + 32 * ty, 31 + 64 * tx
                 img[ys:ys + 32, xs:xs + 64] = strong[ys:ys + 32, xs:xs + 64]
     return img

@@ -1528,11 +1528,12 @@ int orb_prepare(vo_ctx* c, int n_images, int rows, int cols, int step, size_t in
             }
         }
         // FAST tiles: level 0, then the other levels (two launch groups); inside a group the sampled
-        // tiles first (fast_raise_kernel: every eighth tile of a level, on a diagonal pattern so
-        // that they spread over rows and columns; a level of fewer than 24 tiles is sampled whole)
+        // tiles first (fast_raise_kernel: every eighth tile of a level, in horizontal pairs - a lone
+        // 64-pixel tile uses half of the 128-byte lines it touches - on a diagonal pattern so that
+        // they spread over rows and columns; a level of fewer than 24 tiles is sampled whole)
         n.fast_ttab = (uint32_t)tab.size();
         auto sampled = [&](int l, int tx, int ty) {
-            return n.L[l].fast_tx * n.L[l].fast_ty < 24 || (tx + 3 * ty) % 8 == 0;
+            return n.L[l].fast_tx * n.L[l].fast_ty < 24 || ((tx >> 1) + 3 * ty) % 8 == 0;
         };
         for (int l = 0; l < kLevels; ++l) {
             n.L[l].fast_ns = 0;
