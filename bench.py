@@ -64,7 +64,10 @@ def algorithmic_work(h, w, n_images, out, stats):
     writes every level pixel; selection reads every FAST candidate twice (histogram, cut), an
     81-byte Harris window per survivor of the first cut (at most 2 x max_features per image) and
     writes the keypoints; describe reads the 31x31 disc and the 37x37 blurred window of each
-    keypoint and writes 28 + 32 bytes; the matcher compares every query row with every train
+    keypoint and writes 28 + 32 bytes - but the windows of a level's keypoints overlap, so against
+    the HBM ceiling it is charged no more than one read of the pyramid and one of the blurred
+    pyramid (what has to come from memory; the window bytes themselves, served by the caches, are
+    reported beside it as `describe_window_bytes_through_cache`); the matcher compares every query row with every train
     row of its pair; RANSAC tests every candidate model of the hypotheses the serial loop walks
     on every match and solves one five-point problem per hypothesis."""
     lv = level_pixels(h, w)
@@ -75,7 +78,7 @@ def algorithmic_work(h, w, n_images, out, stats):
         "fast": n_images * sum(lv),
         "select": cands * 8 + min(cands, 2.0 * kps) * (81 + 8) + kps * 8,
         "blur": n_images * 2 * sum(lv),
-        "describe": kps * (31 * 31 + 37 * 37 + 60),
+        "describe": min(kps * (31 * 31 + 37 * 37), n_images * 2.0 * sum(lv)) + kps * 60,
         "knn2": KNN_LANE_OPS * float(np.sum(out["n_kp1"].astype(np.float64) * out["n_kp2"])),
         "ratio": float(np.sum(out["n_kp1"])) * 16 + float(np.sum(out["n_matches"])) * 28,
         "ransac_solve": FIVE_POINT_FLOPS * float(np.sum(out["ransac_iters"])),
@@ -433,6 +436,8 @@ def main():
         "scene": scene_stats(stats, out),
         "pipeline": {"kernel_group_ms_per_step_single_stream": kernel_ms,
                      "algorithmic_work_per_step": work,
+                     "describe_window_bytes_through_cache": float(np.sum(out["n_kp1"]) + np.sum(out["n_kp2"]))
+                     * run.n_images / (2.0 * len(out)) * (31 * 31 + 37 * 37),
                      "fraction_of_group_ceiling_single_stream": {
                          g: work[g] / (kernel_ms[g] * 1e-3) / (1e9 if BOUND_OF_GROUP[g] == "hbm" else 1e12) /
                          PEAK[BOUND_OF_GROUP[g]][0] for g in work if kernel_ms[g] > 0}},
