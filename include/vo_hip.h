@@ -285,7 +285,10 @@ int vo_block_range(int n, int part, int parts, int* begin, int* end);
 int vo_debug_level(vo_ctx* ctx, int image, int level, int blurred, uint8_t* out, size_t out_bytes, int* w, int* h);
 /* FAST candidates (after non-max suppression and the 31-pixel border filter)
  * of one level of the most recent detect call as (x, y, score) triples, in no
- * particular order.  Returns the count in *n_out. */
+ * particular order.  Returns the count in *n_out.  After a call that ran with
+ * raised thresholds (vo_debug_fast_thresholds) the list holds every candidate
+ * the selection can keep - all that score at least the level's threshold -
+ * but only some of the weaker ones. */
 int vo_debug_candidates(vo_ctx* ctx, int image, int level, int32_t* out, int cap, int* n_out);
 /* Scene statistics of the FAST stage, for reporting what a benchmark scene looks
  * like: enable != 0 zeroes the counters and makes every following detection add
