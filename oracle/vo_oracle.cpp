@@ -18,7 +18,7 @@
 // contract of the reference's tests (ref:tests/test_feature_detector.cpp,
 // ref:tests/test_feature_matcher.cpp, ref:tests/test_motion_estimator.cpp).
 //
-// Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (see Makefile).
+// Build: g++ -O3 -mavx2 -mpopcnt -std=c++17 -ffp-contract=off -fPIC -shared (see Makefile).
 // -ffp-contract=off matters: float expressions must round after every
 // operation, as a non-FMA x86-64 OpenCV build does.
 
