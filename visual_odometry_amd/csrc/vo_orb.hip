@@ -1005,10 +1005,16 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
     int pitch;
     const uint8_t* base = level_base(g, in, pyr, img, l, &pitch);
     const bool aligned = ((((uintptr_t)base) | (unsigned)pitch) & 3) == 0;
-    // Every tile but a level's last column of tiles reads its source rows straight from global
-    // memory: rows beyond the top / bottom border are reflected per lane, and at the left border
-    // the four columns -4..-1 are the mirror image of columns 4..1 (one v_perm).
-    const bool direct = x0 + BT_W + 4 <= L.w;
+    // Every tile of a level wider than one tile reads its source rows straight from global
+    // memory: rows beyond the top / bottom border are reflected per lane, at the left border the
+    // four columns -4..-1 are the mirror image of columns 4..1 (one v_perm), and in a level's
+    // last column of tiles (`edge`) the one or two dwords of a row that reach past the last
+    // column are picked, with one v_perm, out of the row's last eight bytes - which hold every
+    // column that BORDER_REFLECT_101 can ask for - by the lanes that own them.  (Staging the
+    // whole window of those tiles in LDS byte by byte made them cost 3.5 times a direct tile:
+    // a quarter of the kernel's vector instructions on a seventh of its tiles.)
+    const bool edge = x0 + BT_W + 4 > L.w;
+    const bool direct = !edge || x0 > 0;
 
     const uint32_t t0123 = (uint32_t)tabs.taps[0] | ((uint32_t)tabs.taps[1] << 8) | ((uint32_t)tabs.taps[2] << 16) |
                            ((uint32_t)tabs.taps[3] << 24);
@@ -1035,6 +1041,27 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
 
     if (direct) {
         const bool inner_rows = y0 >= 3 && y0 + BT_H + 3 <= L.h;   // source rows y0 - 3 .. y0 + 60 exist
+        // Edge tiles: v_perm selector of the dword at column x out of the row's bytes w - 8 .. w - 1
+        // (selector bytes 0..3: first dword, 4..7: second), and whether the dword needs it at all.
+        // Columns beyond w + 2 feed no output inside the image; their selector is clamped.
+        const int gx_l = tid & 15;
+        auto edge_sel = [&](int x, bool* fix) -> uint32_t {
+            *fix = edge && x + 3 >= L.w;
+            uint32_t s = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xs = x + b;
+                const int src = xs < L.w ? xs : 2 * (L.w - 1) - xs;
+                s |= (uint32_t)min(max(src - (L.w - 8), 0), 7) << (8 * b);
+            }
+            return s;
+        };
+        bool fix_c = false, fix_h = false;
+        uint32_t sel_c = 0, sel_h = 0;
+        if (edge) {   // workgroup-uniform
+            sel_c = edge_sel(x0 + 4 * gx_l, &fix_c);
+            sel_h = edge_sel(x0 + 4 * gx_l + 4, &fix_h);   // (only lane 15 of a row uses it)
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int item = tid + 256 * it, rp = item >> 4, gx = item & 15;
@@ -1051,12 +1078,27 @@ __global__ __launch_bounds__(256) void blur_kernel(Geom g, SmallTabs tabs, const
             }
             const uint32_t ye = (uint32_t)__mul24(re, pitch), yo = (uint32_t)__mul24(ro, pitch);
             const uint32_t cx = (uint32_t)(x0 + 4 * gx);
-            const uint32_t e1 = load_u32_unaligned(base + ye + cx), o1 = load_u32_unaligned(base + yo + cx);
+            // (a dword that reaches past the last column is loaded from the row's last four bytes
+            // instead - a valid address - and replaced below)
+            uint32_t e1 = load_u32_unaligned(base + ye + (fix_c ? (uint32_t)(L.w - 4) : cx));
+            uint32_t o1 = load_u32_unaligned(base + yo + (fix_c ? (uint32_t)(L.w - 4) : cx));
             uint32_t he = 0, ho = 0;
             if ((gx == 0 && !left) || gx == 15) {
-                const uint32_t hx = gx == 0 ? cx - 4 : cx + 4;
+                const uint32_t hx = gx == 0 ? cx - 4 : (fix_h ? (uint32_t)(L.w - 4) : cx + 4);
                 he = load_u32_unaligned(base + ye + hx);
                 ho = load_u32_unaligned(base + yo + hx);
+            }
+            if (edge) {   // workgroup-uniform
+                const uint32_t ae = load_u32_unaligned(base + ye + (uint32_t)(L.w - 8)), be = load_u32_unaligned(base + ye + (uint32_t)(L.w - 4));
+                const uint32_t ao = load_u32_unaligned(base + yo + (uint32_t)(L.w - 8)), bo = load_u32_unaligned(base + yo + (uint32_t)(L.w - 4));
+                if (fix_c) {
+                    e1 = __builtin_amdgcn_perm(be, ae, sel_c);
+                    o1 = __builtin_amdgcn_perm(bo, ao, sel_c);
+                }
+                if (fix_h && gx == 15) {
+                    he = __builtin_amdgcn_perm(be, ae, sel_h);
+                    ho = __builtin_amdgcn_perm(bo, ao, sel_h);
+                }
             }
             // row_shr:1 / row_shl:1; the lane without a neighbour keeps the halo value
             uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp((int)he, (int)e1, 0x111, 0xF, 0xF, false);
