@@ -9,6 +9,8 @@ O=$R/gpurun_out
 mkdir -p $O
 SHORT="--no-cpu-baseline --no-hamming --no-sequence --no-aux-scene --no-dropin"
 
+# (the counter calibration program is a built file that is not kept in history)
+[ -x $R/tools/calib_fetch ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/calib_fetch.hip -o $R/tools/calib_fetch
 echo "[collect] default bench line"; date +%T
 timeout -k 10 400 python3 $R/bench.py > $O/bench_final.json 2> $O/bench_final.err
 echo "[collect] rocprofv3 kernel statistics: default command"; date +%T
