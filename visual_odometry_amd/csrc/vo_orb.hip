@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
     if (!(head >> 31)) {
         const uint4 sel = *reinterpret_cast<const uint4*>(gt + 4), cf = *reinterpret_cast<const uint4*>(gt + 8);
         uint32_t a[RS_ROWS][2], b[RS_ROWS][2];
+        uint32_t prev_sy1 = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < RS_ROWS; ++j) {
             // 32-bit offsets from the wave-uniform image base (24-bit multiplies: rows and
@@ -117,10 +118,19 @@ __global__ __launch_bounds__(256) void resize_kernel(Geom g, int l, const uint8_
             uint32_t sy = ty[j] >> 16, sy1 = min(sy + 1u, (uint32_t)(S.h - 1));
             uint32_t o0 = __umul24(sy, (uint32_t)spitch) + (uint32_t)sx0;
             uint32_t o1 = __umul24(sy1, (uint32_t)spitch) + (uint32_t)sx0;
-            a[j][0] = load_u32_unaligned(src + o0);
-            a[j][1] = load_u32_unaligned(src + (o0 + 4u));
+            // With a scale of 1.2 four of five output rows start at the source row the previous one
+            // ended on: that row is in registers already.  (The kernel is bound by the texture
+            // addresser: every load instruction it does not issue counts.)
+            if (sy == prev_sy1) {
+                a[j][0] = b[j > 0 ? j - 1 : 0][0];
+                a[j][1] = b[j > 0 ? j - 1 : 0][1];
+            } else {
+                a[j][0] = load_u32_unaligned(src + o0);
+                a[j][1] = load_u32_unaligned(src + (o0 + 4u));
+            }
             b[j][0] = load_u32_unaligned(src + o1);
             b[j][1] = load_u32_unaligned(src + (o1 + 4u));
+            prev_sy1 = sy1;
         }
         const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w}, cc[4] = {cf.x, cf.y, cf.z, cf.w};
 #pragma unroll
