@@ -20,6 +20,7 @@
 #include <visual_odometry/motion_estimator.hpp>
 #include <visual_odometry/sequence_pipeline.hpp>
 #include <visual_odometry/trajectory.hpp>
+#include <vo_hip.h>
 
 namespace {
 
@@ -128,8 +129,14 @@ int main(int argc, char** argv) {
     std::cout << "\nProcessing " << max_pairs << " frame pairs...\n";
 
     std::vector<int> devices;
-    if (opt->gpus > 1)
+    if (opt->gpus > 1) {
+        int const have = vo_device_count();
+        if (opt->gpus > have) {
+            std::cerr << "Error: --gpus " << opt->gpus << " but this machine has " << have << " GPU(s)\n";
+            return 1;
+        }
         for (int d = 0; d < opt->gpus; ++d) devices.push_back(d);
+    }
 
     int valid_motions = 0;
     // one pair's outcome, reported and accumulated in pair order

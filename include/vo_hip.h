@@ -70,6 +70,8 @@ enum {
 };
 
 /* --- context ------------------------------------------------------------- */
+/* Number of GPUs a context can be created on (0 if the HIP runtime finds none). */
+int vo_device_count(void);
 int vo_ctx_create(int device, vo_ctx** out);
 void vo_ctx_destroy(vo_ctx* ctx);
 /* Message of the last failing call on this context ("" if none). */
@@ -117,6 +119,45 @@ enum {
 int vo_set_timing(vo_ctx* ctx, int groups);
 float vo_kernel_time_ms(vo_ctx* ctx, int group, int* launches);
 
+/* Per-context switches (no counterpart in the reference, whose functions take
+ * only the config structs of ref:include/visual_odometry/feature_detector.hpp:24-26,
+ * feature_matcher.hpp:26-28, motion_estimator.hpp:48-51).  None of them changes a
+ * result except VO_OPT_FIVE_POINT_LITERAL; the others pick between kernels that
+ * must agree bit for bit, for tests and measurements.  A context takes its
+ * defaults once, in vo_ctx_create, from the environment variable named with
+ * each option (unset: the value marked default); after that only
+ * vo_ctx_set_option changes them.  Options are read when a call enqueues work,
+ * so set them between calls, from the thread that owns the context. */
+enum {
+    /* 1: the minimal solver as cv::findEssentialMat runs it (one chart of the
+     * null space, the roots as they come, no refinement, no duplicate removal,
+     * no second chart); 0 (default): complete, refined solution sets.
+     * Environment: VO_FIVE_POINT_LITERAL. */
+    VO_OPT_FIVE_POINT_LITERAL = 0,
+    /* FAST with per-(image, level) raised thresholds: -1 (default) decided by
+     * the batch size, 0 never, 1 always.  Environment: VO_FAST_RAISE. */
+    VO_OPT_FAST_RAISE = 1,
+    /* Hamming search kernel: -1 (default) by size, 0 the scalar-operand kernel,
+     * 1 the LDS-broadcast kernel.  Environment: VO_KNN_MODE. */
+    VO_OPT_KNN_MODE = 2,
+    /* Wavefronts per workgroup of the LDS-broadcast kernel: 0 (default) by
+     * size, else 1, 4, 8 or 16.  Environment: VO_KNN_NW. */
+    VO_OPT_KNN_WAVES = 3,
+    /* Queries per lane of the scalar-operand kernel: 0 (default) by size, else
+     * 1, 2 or 4.  Environment: VO_KNN_QPL. */
+    VO_OPT_KNN_QUERIES_PER_LANE = 4,
+    /* 0: skip the second-chart pass of the five-point solver (measurement aid;
+     * changes results); 1 (default).  Environment: VO_SECOND_CHART. */
+    VO_OPT_SECOND_CHART = 5,
+    /* Train-set chunks a single Hamming search is split into (grid = query
+     * blocks x chunks, merged by a second kernel): 0 (default) by size, 1 never,
+     * else 2..64.  Environment: VO_KNN_SPLIT. */
+    VO_OPT_KNN_TRAIN_SPLIT = 6,
+    VO_OPT_COUNT = 7
+};
+int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
+int vo_ctx_get_option(const vo_ctx* ctx, int option, int* value);
+
 /* --- detect_features / detect_keypoints_only -------------------------------
  * Replaces visual_odometry::detect_features (ref:src/feature_detector.cpp:12-18,
  * decl ref:include/visual_odometry/feature_detector.hpp:36) and, with
@@ -147,6 +188,27 @@ int vo_hamming_knn2(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int
                     int32_t* dist2);
 int vo_hamming_knn2_dev(vo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                         int32_t* d_idx2, int32_t* d_dist2);
+
+/* The same search over several GPUs of one node, for descriptor sets so large
+ * that one search is worth sharding (the reference's knnMatch call,
+ * ref:src/feature_matcher.cpp:26-30, is one serial scan): ctxs[k], one context
+ * per GPU created by the caller, takes the query rows
+ * vo_block_range(nq, k, n_ctx, ...); the train set is replicated; a query's two
+ * nearest rows are complete inside its block, so nothing is reduced - the
+ * blocks' rows are only brought together.  Results are those of one
+ * vo_hamming_knn2 call.
+ * vo_hamming_knn2_multi: host buffers; one host thread per context uploads,
+ * searches and downloads into rows [begin, end) of idx2 / dist2; returns when
+ * they are complete.
+ * vo_hamming_knn2_multi_dev: d_q[k] = block k's query rows on ctxs[k]'s GPU,
+ * d_t[k] = the whole train set on that GPU (16-byte aligned), d_idx2 / d_dist2
+ * = the full nq x 2 tables on ctxs[0]'s GPU; every other context sends its rows
+ * there with one peer copy per table on its own stream (the path's single
+ * exchange step).  Only enqueues; complete after vo_sync() on every context. */
+int vo_hamming_knn2_multi(vo_ctx* const* ctxs, int n_ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                          int32_t* idx2, int32_t* dist2);
+int vo_hamming_knn2_multi_dev(vo_ctx* const* ctxs, int n_ctx, const uint8_t* const* d_q, int nq,
+                              const uint8_t* const* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2);
 
 /* The whole of match_features (ref:src/feature_matcher.cpp:15-42): kNN(2),
  * Lowe ratio test `d0 < ratio * d1` in float32, survivors in query order.

@@ -26,3 +26,18 @@ def ctx():
     c = capi.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def options(ctx):
+    """options(name, value) sets a per-context switch (vo_ctx_set_option) for the rest of the test;
+    whatever a test changed is put back afterwards."""
+    before = {}
+
+    def set_option(name, value):
+        before.setdefault(name, ctx.get_option(name))
+        ctx.set_option(name, value)
+
+    yield set_option
+    for name, value in before.items():
+        ctx.set_option(name, value)

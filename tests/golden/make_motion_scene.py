@@ -5,6 +5,13 @@ The reference draws them from std::mt19937(42) through libstdc++'s
 uniform_real_distribution<double>; both are restated here: numpy's legacy
 MT19937 seeding equals std::mt19937's, and libstdc++'s generate_canonical for a
 32-bit engine is (r1 + r2 * 2^32) / 2^64 evaluated in double.
+
+The reference passes the three draws of a point as constructor arguments
+(ref:tests/test_motion_estimator.cpp:39-40), whose evaluation order the language
+leaves open: clang (the reference's configured compiler) evaluates them left to
+right - x, y, z, the files motion_scene_<name>.npz -, g++ right to left - z, y, x,
+the files motion_scene_<name>_zyx.npz (first point x = 879.69 instead of 896.54;
+tests/test_oracle_cpu.py checks that against a g++ build of the same expression).
 """
 import os
 
@@ -13,7 +20,7 @@ import numpy as np
 FX, FY, CX, CY = 718.856, 718.856, 607.1928, 185.2157
 
 
-def scene(R, t, n=100):
+def scene(R, t, n=100, order="xyz"):
     raw = np.random.RandomState(42)._bit_generator.random_raw(6 * n).astype(np.float64)
     it = iter(raw)
 
@@ -24,9 +31,14 @@ def scene(R, t, n=100):
 
     p1s, p2s = [], []
     for _ in range(n):
-        x = canon() * (1100 - 100) + 100
-        y = canon() * (300 - 50) + 50
-        z = canon() * (50 - 5) + 5
+        if order == "xyz":
+            x = canon() * (1100 - 100) + 100
+            y = canon() * (300 - 50) + 50
+            z = canon() * (50 - 5) + 5
+        else:
+            z = canon() * (50 - 5) + 5
+            y = canon() * (300 - 50) + 50
+            x = canon() * (1100 - 100) + 100
         P = np.array([x - CX, y - CY, z])
         P[0] *= P[2] / FX
         P[1] *= P[2] / FY
@@ -45,15 +57,17 @@ def main():
     # EstimatesForwardMotion
     R = np.eye(3)
     t = np.array([0.0, 0.0, 1.0])
-    p1, p2 = scene(R, t)
-    np.savez(os.path.join(here, "motion_scene_forward.npz"), p1=p1, p2=p2, R=R, t=t)
+    for order, tag in (("xyz", ""), ("zyx", "_zyx")):
+        p1, p2 = scene(R, t, order=order)
+        np.savez(os.path.join(here, f"motion_scene_forward{tag}.npz"), p1=p1, p2=p2, R=R, t=t)
     # EstimatesRotation: Ry(0.05), t = normalised (0.1, 0, 1)
     a = 0.05
     R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
     t = np.array([0.1, 0.0, 1.0])
     t /= np.linalg.norm(t)
-    p1, p2 = scene(R, t)
-    np.savez(os.path.join(here, "motion_scene_rotation.npz"), p1=p1, p2=p2, R=R, t=t)
+    for order, tag in (("xyz", ""), ("zyx", "_zyx")):
+        p1, p2 = scene(R, t, order=order)
+        np.savez(os.path.join(here, f"motion_scene_rotation{tag}.npz"), p1=p1, p2=p2, R=R, t=t)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,153 @@
+"""GPU parity of the OpenCV-literal RANSAC mode (VO_OPT_FIVE_POINT_LITERAL = 1 on the GPU,
+oracle.set_variant(five_point_literal=True) on the CPU): the minimal solver as
+cv::findEssentialMat runs it (ref:src/motion_estimator.cpp:69-71) - one chart of the null space,
+the real roots of the hidden-variable polynomial as they come, no refinement, no duplicate removal,
+no second chart.  The default mode's tests (tests/test_gpu_parity.py) are repeated here.
+
+What can be identical is: the sample index sets, the iteration count, the inlier count and mask,
+the pose.  The winning model itself is compared to 1e-6 only: without the refinement a model is
+as accurate as the 10 x 10 elimination that produced its root, and the two sides eliminate in
+different bases of the same null space (Householder vectors on the GPU, SVD vectors in the
+oracle), so their unrefined models agree to the elimination's conditioning, not to rounding."""
+import os
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KITTI_K = synth.KITTI_K
+TUM_K = synth.TUM_K
+E_TOL = 1e-6
+
+
+def _rot_err_deg(R1, R2):
+    c = (np.trace(R1.T @ R2) - 1) / 2
+    return np.degrees(np.arccos(np.clip(c, -1, 1)))
+
+
+@pytest.fixture
+def literal(ctx, oracle, options):
+    options("five_point_literal", 1)
+    oracle.set_variant(five_point_literal=True)
+    yield
+    oracle.set_variant()
+
+
+def _matched_points(oracle, seed, nfeat=2000):
+    a, b = synth.frame_pair(seed)
+    ka, da = oracle.orb_detect(a, nfeat)
+    kb, db = oracle.orb_detect(b, nfeat)
+    qi, ti, _ = oracle.match(da, db)
+    return np.stack([ka["x"][qi], ka["y"][qi]], 1), np.stack([kb["x"][ti], kb["y"][ti]], 1)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_find_essential_shared_hypotheses(ctx, oracle, literal, seed):
+    p1, p2 = _matched_points(oracle, seed)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, TUM_K)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, TUM_K)
+    assert git == oit
+    assert np.array_equal(gsamp, osamp)
+    assert gg == og
+    assert np.array_equal(gm, om)
+    s = 1.0 if np.sum(gE * oE) > 0 else -1.0
+    assert np.max(np.abs(gE - s * oE)) < E_TOL
+
+
+@pytest.mark.parametrize("fixed", [64, 700])
+def test_find_essential_fixed_hypothesis_count(ctx, oracle, literal, fixed):
+    p1, p2 = _matched_points(oracle, 24, 1000)
+    rng = np.random.default_rng(3)
+    bad = rng.random(len(p1)) < 0.4
+    p2 = p2.copy()
+    p2[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2)).astype(np.float32)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, TUM_K, fixed_iters=fixed)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, TUM_K, fixed_iters=fixed)
+    assert git == oit == fixed
+    assert np.array_equal(gsamp, osamp)
+    assert gg == og and np.array_equal(gm, om)
+
+
+@pytest.mark.parametrize("seed", [21, 25, 26])
+def test_estimate_motion_matches_oracle(ctx, oracle, literal, seed):
+    p1, p2 = _matched_points(oracle, seed)
+    g = ctx.estimate_motion(p1, p2, TUM_K)
+    o = oracle.estimate_motion(p1, p2, TUM_K)
+    assert g["valid"] == o["valid"] and g["valid"]
+    assert g["inliers"] == o["inliers"]
+    assert np.array_equal(g["mask"], o["mask"])
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01
+    assert np.linalg.norm(g["t"] - o["t"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["forward", "rotation", "forward_zyx", "rotation_zyx"])
+def test_reference_motion_scenes(ctx, oracle, literal, name):
+    # ref:tests/test_motion_estimator.cpp:61-102 (the _zyx files: the points a g++ build draws)
+    z = np.load(os.path.join(GOLD, f"motion_scene_{name}.npz"))
+    g = ctx.estimate_motion(z["p1"], z["p2"], KITTI_K)
+    o = oracle.estimate_motion(z["p1"], z["p2"], KITTI_K)
+    assert g["valid"] and g["inliers"] > 50
+    if name.startswith("forward"):
+        assert g["t"][2] > 0.9
+    assert g["inliers"] == o["inliers"]
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01
+    assert np.linalg.norm(g["t"] - o["t"]) < 1e-4
+    assert _rot_err_deg(g["R"], z["R"]) < 0.01 and np.linalg.norm(g["t"] - z["t"]) < 1e-4
+
+
+def test_c1_sequence_of_101_frames_1000_keypoints(ctx, oracle, literal):
+    """The reference's CPU-runnable configuration (ref:src/main.cpp:144-184: 640x480,
+    orb_matcher{1000}, 100 consecutive pairs) through vo_pipeline_sequence_dev in the literal mode:
+    every fifth pair's record against the oracle."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = synth.sequence(0x5EED0000, 101)
+    seq = torch.from_numpy(np.stack(frames)).cuda()
+    res = torch.zeros(100 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_sequence_dev(seq.data_ptr(), 101, 480, 640, 640, 480 * 640, 1000, 0.75, TUM_K, 1.0, 0.999, 0,
+                              res.data_ptr())
+    ctx.sync()
+    out = np.frombuffer(res.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    assert out["valid"].mean() > 0.9 and (out["status"] == 0).all()
+    det = {}
+
+    def detect(i):
+        if i not in det:
+            det[i] = oracle.orb_detect(frames[i], 1000)
+        return det[i]
+
+    for p in range(0, 100, 5):
+        (ka, da), (kb, db) = detect(p), detect(p + 1)
+        qi, ti, _ = oracle.match(da, db)
+        p1 = np.stack([ka["x"][qi], ka["y"][qi]], 1)
+        p2 = np.stack([kb["x"][ti], kb["y"][ti]], 1)
+        o = oracle.estimate_motion(p1, p2, TUM_K)
+        _, _, _, oit, _ = oracle.find_essential(p1, p2, TUM_K)
+        r = out[p]
+        assert (r["n_kp1"], r["n_kp2"], r["n_matches"]) == (len(ka), len(kb), len(qi)), p
+        assert r["ransac_iters"] == oit, p
+        assert bool(r["valid"]) == o["valid"] and r["inliers"] == o["inliers"], p
+        if o["valid"]:
+            assert _rot_err_deg(r["R"].reshape(3, 3), o["R"]) < 0.01 and np.linalg.norm(r["t"] - o["t"]) < 1e-4, p
+
+
+def test_full_hd_pair_fixed_4096_hypotheses(ctx, oracle, literal):
+    """One 1080p / 10 000-keypoint pair with 4096 fixed hypotheses (no early exit)."""
+    a, b = synth.frame_pair(61, height=1080, width=1920)
+    K = synth.default_K(1920, 1080)
+    ga, gda = ctx.orb_detect(a, 10000)
+    gb, gdb = ctx.orb_detect(b, 10000)
+    gq, gt, _ = ctx.match_ratio(gda, gdb)
+    p1 = np.stack([ga["x"][gq], ga["y"][gq]], 1)
+    p2 = np.stack([gb["x"][gt], gb["y"][gt]], 1)
+    og, oE, om, oit, osamp = oracle.find_essential(p1, p2, K, fixed_iters=4096)
+    gg, gE, gm, git, gsamp = ctx.find_essential(p1, p2, K, fixed_iters=4096)
+    assert git == oit == 4096 and np.array_equal(gsamp, osamp)
+    assert gg == og and np.array_equal(gm, om)
+    g = ctx.estimate_motion(p1, p2, K, fixed_iters=4096)
+    o = oracle.estimate_motion(p1, p2, K, fixed_iters=4096)
+    assert g["valid"] and g["inliers"] == o["inliers"]
+    assert _rot_err_deg(g["R"], o["R"]) < 0.01 and np.linalg.norm(g["t"] - o["t"]) < 1e-4

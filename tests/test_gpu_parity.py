@@ -34,16 +34,17 @@ def test_knn2_matches_oracle(ctx, oracle, nq, nt):
     assert np.array_equal(gd, od)
 
 
-@pytest.mark.parametrize("knob", ["VO_KNN_NW=1", "VO_KNN_NW=4", "VO_KNN_NW=8", "VO_KNN_NW=16", "VO_KNN_MODE=0",
-                                  "VO_KNN_QPL=2", "VO_KNN_QPL=4"])
+@pytest.mark.parametrize("knob", ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_waves=16", "knn_mode=0",
+                                  "knn_queries_per_lane=2", "knn_queries_per_lane=4", "knn_train_split=2",
+                                  "knn_train_split=5", "knn_train_split=64"])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (70, 3), (300, 257), (2000, 2000), (1500, 70000)])
-def test_knn2_every_launch_variant(ctx, oracle, monkeypatch, knob, nq, nt):
+def test_knn2_every_launch_variant(ctx, oracle, options, knob, nq, nt):
     """The matcher picks its kernel and workgroup size from the problem size (one wavefront per
     workgroup only for batches of several hundred pairs, the scalar-operand kernels only beyond
     65 536 train rows): every variant is forced here, on shapes with ragged last blocks, ties at
     distance 0 and a train set longer than one 65 536-row chunk."""
     name, value = knob.split("=")
-    monkeypatch.setenv(name, value)   # read by the library at every launch
+    options(name, int(value))
     q = synth.descriptors(300 + nq, nq, dup_fraction=0.2)
     t = synth.descriptors(400 + nt, nt, dup_fraction=0.3)
     if nt > 100 and nq > 50:
@@ -115,6 +116,93 @@ def test_c4_full_size_65536x65536(ctx, oracle):
     assert list(gi[planted[0]]) == [0, 65535] and list(gd[planted[0]]) == [0, 0]
     assert list(gi[planted[4]]) == [32767, 32768]
     assert list(gi[planted[8]]) == [1, 65534]
+
+
+def _c4_descriptors(nq, nt):
+    q = synth.descriptors(7, nq)
+    t = synth.descriptors(8, nt)
+    for k in range(1, 64):                     # a distance-0 pair across every 64th of the train set
+        t[k * (nt // 64) - 1] = q[64 + k]      # (the chunk boundaries of a split search)
+        t[k * (nt // 64)] = q[64 + k]
+    t[0] = q[0]                                # ... at both ends of the train set
+    t[nt - 1] = q[0]
+    t[nt // 2 - 1] = q[nq // 2]
+    t[nt // 2] = q[nq // 2]
+    t[nt - 2] = q[nq - 1]
+    t[1] = q[nq - 1]
+    return q, t
+
+
+def test_c4_shard_of_8192_query_rows_is_split_over_the_train_set(ctx, oracle, options):
+    """One rank's share of the 65 536 x 65 536 match: 8 192 query rows are 128 workgroups, too few
+    for 256 compute units, so the library also splits the train set (grid = query blocks x chunks,
+    per-chunk top two merged by key).  The result must equal the unsplit search bit for bit -
+    checked on every row against a forced single-chunk run, and on sampled rows (tied pairs that
+    straddle chunk boundaries among them) against the oracle."""
+    import torch
+    nq, nt = 8192, 65536
+    q, t = _c4_descriptors(nq, nt)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+
+    def run():
+        idx = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+        dst = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+        ctx.hamming_knn2_dev(dq.data_ptr(), nq, dt.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+        ctx.sync()
+        return idx.cpu().numpy(), dst.cpu().numpy()
+
+    gi, gd = run()                             # the library's own choice: split
+    options("knn_train_split", 1)
+    wi, wd = run()
+    assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+    for split in (3, 8, 64):
+        options("knn_train_split", split)
+        si, sd = run()
+        assert np.array_equal(si, wi) and np.array_equal(sd, wd), split
+    rows = np.unique(np.concatenate([np.arange(0, 192), np.arange(nq - 64, nq), [nq // 2],
+                                     np.random.default_rng(5).integers(0, nq, 1000)]))
+    oi, od = oracle.knn2(q[rows], t)
+    assert np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od)
+    assert list(gi[0]) == [0, nt - 1] and list(gd[0]) == [0, 0]
+    assert list(gi[nq // 2]) == [nt // 2 - 1, nt // 2]
+    assert list(gi[64 + 5]) == [5 * (nt // 64) - 1, 5 * (nt // 64)]
+
+
+@pytest.mark.parametrize("n_ctx,nq,nt", [(2, 4096, 8192), (3, 1000, 3000), (4, 3, 70), (8, 16384, 16384)])
+def test_knn2_over_several_contexts_equals_one(ctx, oracle, n_ctx, nq, nt):
+    """vo_hamming_knn2_multi / _multi_dev: query rows in contiguous blocks over several contexts
+    (here all on the one GPU of the box; on a node one per GPU), train set replicated, every block's
+    rows sent to their place in the first context's tables.  Equal to one context's search."""
+    import torch
+    from visual_odometry_amd import capi
+    q = synth.descriptors(900 + nq, nq, dup_fraction=0.2)
+    t = synth.descriptors(901 + nt, nt, dup_fraction=0.2)
+    if nt > 100 and nq > 50:
+        t[-50:] = q[:50]
+        t[7:57] = q[:50]
+    wi, wd = ctx.hamming_knn2(q, t)
+    oi, od = oracle.knn2(q[: min(nq, 1500)], t)
+    assert np.array_equal(wi[: len(oi)], oi) and np.array_equal(wd[: len(od)], od)
+    ctxs = [capi.Context(0) for _ in range(n_ctx)]
+    try:
+        gi, gd = capi.hamming_knn2_multi(ctxs, q, t)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd)
+        dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+        copies = [dt.clone() for _ in range(n_ctx)]                    # one replica per context
+        blocks = [capi.block_range(nq, k, n_ctx) for k in range(n_ctx)]
+        parts = [dq[b:e].clone() if e > b else dq[:1].clone() for b, e in blocks]
+        idx = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+        dst = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for rep in range(2):                                           # back to back: the per-context tables are reused
+            capi.hamming_knn2_multi_dev(ctxs, [p.data_ptr() for p in parts], nq, [c.data_ptr() for c in copies], nt,
+                                        idx.data_ptr(), dst.data_ptr())
+        for c in ctxs:
+            c.sync()
+        assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(dst.cpu().numpy(), wd)
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 @pytest.mark.parametrize("ratio", [0.5, 0.75, 0.9])
@@ -226,19 +314,19 @@ def _strong_texture_on_sampled_tiles(seed, height=480, width=640):
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 300), ("checker", 2000), ("kitti", 4000),
                                         ("odd", 500), ("narrow", 300), ("threshold", 800), ("sampled_strong", 2000),
                                         ("sampled_strong", 500)])
-def test_orb_detect_with_raised_fast_thresholds(ctx, oracle, monkeypatch, name, nfeat):
+def test_orb_detect_with_raised_fast_thresholds(ctx, oracle, options, name, nfeat):
     """Batched calls run most FAST tiles with a per-(image, level) threshold raised towards the
     score cut of the selection; forced here on single images.  The keypoints and descriptors must
     not change, the candidate lists may only lose candidates, and both outcomes - threshold kept,
     tiles run again - must occur."""
     img = _strong_texture_on_sampled_tiles(21) if name == "sampled_strong" else IMAGES[name]()
-    monkeypatch.setenv("VO_FAST_RAISE", "1")
+    options("fast_raise", 1)
     gk, gd = ctx.orb_detect(img, nfeat)
     info = ctx.fast_thresholds(0)
     assert info is not None
     thr, redo = info
     cands = [ctx.debug_candidates(0, l) for l in range(8)]
-    monkeypatch.setenv("VO_FAST_RAISE", "0")
+    options("fast_raise", 0)
     pk, pd = ctx.orb_detect(img, nfeat)
     assert ctx.fast_thresholds(0) is None
     ok, od = oracle.orb_detect(img, nfeat)
@@ -260,7 +348,7 @@ def test_orb_detect_with_raised_fast_thresholds(ctx, oracle, monkeypatch, name, 
         assert thr[0] > 20 and redo[0]
 
 
-def test_pipeline_with_and_without_raised_fast_thresholds(ctx, monkeypatch):
+def test_pipeline_with_and_without_raised_fast_thresholds(ctx, options):
     """The batched pipeline raises the thresholds by itself from a dozen images on; its records
     must not depend on it."""
     import torch
@@ -271,11 +359,8 @@ def test_pipeline_with_and_without_raised_fast_thresholds(ctx, monkeypatch):
     imgs = torch.from_numpy(np.stack(frames)).cuda()
     K = synth.default_K(640, 480)
     out = []
-    for flag in ("0", "1", None):
-        if flag is None:
-            monkeypatch.delenv("VO_FAST_RAISE")
-        else:
-            monkeypatch.setenv("VO_FAST_RAISE", flag)
+    for flag in (0, 1, None):
+        options("fast_raise", -1 if flag is None else flag)
         res = torch.zeros(8 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
         ctx.pipeline_pairs_dev(imgs.data_ptr(), 8, 480, 640, 640, 480 * 640, 2000, 0.75, K, 1.0, 0.999, 0, res.data_ptr())
         ctx.sync()
@@ -391,6 +476,36 @@ def test_truncated_keypoint_lists_are_reported_on_the_device_resident_path(ctx, 
     with pytest.raises(capi.VoError, match=stage):              # host-buffer entry point: error code
         ctx.orb_detect(a, 2000)
     ctx.sync()
+
+
+def test_host_calls_report_only_their_own_truncation(ctx, oracle):
+    """A device-resident call that cut a list and has not been synchronised yet must not make the next
+    host-buffer call on clean images fail (that call answers for its own images only), and a
+    host-buffer call on a tie-heavy image returns VO_ERR_CAPACITY together with the lists it kept."""
+    import torch
+    from visual_odometry_amd import capi
+    ties = _dot_grid(12)
+    a, b = synth.frame_pair(9)
+    imgs = torch.from_numpy(np.stack([ties, a])).cuda()
+    res = torch.zeros(capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_pairs_dev(imgs.data_ptr(), 1, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0, res.data_ptr())
+    k1, k2, qi, ti, d = ctx.match_images(a, b, 2000)              # clean pair: no error
+    ok1, od1 = oracle.orb_detect(a, 2000)
+    ok2, od2 = oracle.orb_detect(b, 2000)
+    oq, ot, od = oracle.match(od1, od2)
+    assert k1.tobytes() == ok1.tobytes() and k2.tobytes() == ok2.tobytes()
+    assert np.array_equal(qi, oq) and np.array_equal(ti, ot) and np.array_equal(d, od)
+    gk, gd = ctx.orb_detect(a, 2000)
+    assert gk.tobytes() == ok1.tobytes() and np.array_equal(gd, od1)
+    with pytest.raises(capi.VoError, match="Harris selection"):   # the earlier call's report is still due
+        ctx.sync()
+    with pytest.raises(capi.VoError, match="Harris selection"):
+        ctx.match_images(ties, ties, 2000)
+    k1, k2, qi, ti, d = ctx.match_images(ties, ties, 2000, allow_truncated=True)
+    assert len(k1) == len(k2) > 434 + 256 and k1.tobytes() == k2.tobytes()   # (identical dots: no match passes the ratio test)
+    gk, gd = ctx.orb_detect(ties, 2000, allow_truncated=True)
+    assert gk.tobytes() == k1.tobytes() and len(gd) == len(gk)
+    ctx.sync()                                                    # host-buffer calls leave nothing pending
 
 
 # ------------------------------------------------------------------ RANSAC / pose
@@ -798,7 +913,7 @@ def test_pipeline_tied_responses_return_more_than_max_features(ctx, oracle, nfea
 
 
 @pytest.mark.gpu
-def test_pipeline_results_do_not_depend_on_matcher_variant(ctx, monkeypatch):
+def test_pipeline_results_do_not_depend_on_matcher_variant(ctx):
     """The batched matcher launch (per-pair counts, strided descriptor tables) with every kernel
     variant forced: the pair records must be byte-identical to the default launch's, which the
     tests above check against the oracle."""
@@ -818,11 +933,13 @@ def test_pipeline_results_do_not_depend_on_matcher_variant(ctx, monkeypatch):
 
     want = run()
     assert np.frombuffer(want, capi.PAIR_DTYPE)["n_matches"].min() > 50
-    for knob in ["VO_KNN_NW=1", "VO_KNN_NW=4", "VO_KNN_NW=8", "VO_KNN_MODE=0", "VO_KNN_QPL=2", "VO_KNN_QPL=4"]:
+    for knob in ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_mode=0", "knn_queries_per_lane=2",
+                 "knn_queries_per_lane=4"]:
         name, value = knob.split("=")
-        monkeypatch.setenv(name, value)
+        before = ctx.get_option(name)
+        ctx.set_option(name, int(value))
         assert run() == want, knob
-        monkeypatch.delenv(name)
+        ctx.set_option(name, before)
 
 
 @pytest.mark.gpu

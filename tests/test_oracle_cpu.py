@@ -213,18 +213,80 @@ def _rot_err_deg(R1, R2):
     return np.degrees(np.arccos(np.clip(c, -1, 1)))
 
 
-@pytest.mark.parametrize("name", ["forward", "rotation"])
+# (the _zyx files hold the points a g++ build of the reference's test draws, the others a clang build's)
+@pytest.mark.parametrize("name", ["forward", "rotation", "forward_zyx", "rotation_zyx"])
 def test_reference_motion_scenes(oracle, name):
     z = np.load(os.path.join(GOLD, f"motion_scene_{name}.npz"))
     r = oracle.estimate_motion(z["p1"], z["p2"], KITTI_K)
     assert r["valid"] and r["inliers"] > 50
-    if name == "forward":
+    if name.startswith("forward"):
         assert r["t"][2] > 0.9
     # stronger than the reference: the known ground truth is recovered
     assert _rot_err_deg(r["R"], z["R"]) < 0.01
     assert np.linalg.norm(r["t"] - z["t"]) < 1e-4
     assert abs(np.linalg.norm(r["t"]) - 1) < 1e-12
     assert abs(np.linalg.det(r["R"]) - 1) < 1e-9
+
+
+def test_motion_fixture_draw_orders_are_the_two_compilers(tmp_path):
+    """ref:tests/test_motion_estimator.cpp:39-40 passes dist_x(rng), dist_y(rng), dist_z(rng) as the
+    arguments of one constructor call; the order in which they are evaluated is unspecified.  A g++
+    build of that expression (compiled here) gives the first point of the _zyx fixtures, a
+    brace-initialised (left-to-right by rule) one the first point of the plain fixtures."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "draw.cpp"
+    src.write_text("""
+#include <cstdio>
+#include <random>
+struct V { double x, y, z; V(double a, double b, double c) : x(a), y(b), z(c) {} };
+int main() {
+    std::mt19937 r1(42), r2(42);
+    std::uniform_real_distribution<double> dx(100, 1100), dy(50, 300), dz(5, 50);
+    V call(dx(r1), dy(r1), dz(r1));      // unspecified order
+    V brace{dx(r2), dy(r2), dz(r2)};     // left to right
+    std::printf("%.17g %.17g %.17g %.17g %.17g %.17g\\n", call.x, call.y, call.z, brace.x, brace.y, brace.z);
+}
+""")
+    exe = tmp_path / "draw"
+    subprocess.check_call(["g++", "-O0", "-o", str(exe), str(src)])
+    v = [float(x) for x in subprocess.check_output([str(exe)]).split()]
+    plain = np.load(os.path.join(GOLD, "motion_scene_forward.npz"))["p1"][0]
+    zyx = np.load(os.path.join(GOLD, "motion_scene_forward_zyx.npz"))["p1"][0]
+    # the first image point of a scene is the drawn (x, y) itself, rounded to float
+    assert np.allclose(v[3:5], plain, rtol=1e-6) and np.allclose(v[0:2], zyx, rtol=1e-6)
+    assert abs(plain[0] - 896.54297) < 1e-3 and abs(zyx[0] - 879.691) < 1e-3
+
+
+def _pattern_table(path):
+    import re
+    txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return np.array([int(v) for v in re.findall(r"-?\d+", txt)], np.int64)
+
+
+def test_rbrief_pattern_is_pinned():
+    """The 256 x 4 rBRIEF test table is the one piece of OpenCV's ORB that a third party publishes as
+    data: scikit-image ships its copy of bit_pattern_31_ as orb_descriptor_positions.txt.  Where that
+    file exists (skimage itself need not be importable) the table is compared entry for entry;
+    everywhere, a digest taken when that comparison held pins the table against later edits, and the
+    oracle's and the GPU library's copies must be the same."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ours = _pattern_table(os.path.join(root, "oracle", "orb_pattern.inc"))
+    gpu = _pattern_table(os.path.join(root, "visual_odometry_amd", "csrc", "orb_pattern.inc"))
+    assert ours.shape == (1024,) and np.array_equal(ours, gpu)
+    assert hashlib.sha256(ours.astype("<i1").tobytes()).hexdigest() == \
+        "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    found = glob.glob("/opt/conda/lib/python3*/site-packages/skimage/feature/orb_descriptor_positions.txt") + \
+        glob.glob("/usr/lib/python3*/site-packages/skimage/feature/orb_descriptor_positions.txt")
+    if not found:
+        pytest.skip("no scikit-image data file here: the digest above is the pin")
+    sk = np.loadtxt(found[0])
+    assert sk.shape == (256, 4) and np.array_equal(sk, np.round(sk))
+    assert np.array_equal(ours.reshape(256, 4), sk.astype(np.int64))
 
 
 def test_too_few_points_invalid(oracle):

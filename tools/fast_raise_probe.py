@@ -23,11 +23,11 @@ from visual_odometry_amd import capi, synth  # noqa: E402
 ctx = capi.Context(0)
 for k in range(args.images):
     img = synth.frame_pair(500 + k, sparse=args.sparse)[0] if args.sparse else synth.frame_pair(500 + k)[0]
-    os.environ["VO_FAST_RAISE"] = "1"
+    ctx.set_option("fast_raise", 1)
     ctx.orb_detect(img, 2000)
     thr, redo = ctx.fast_thresholds(0)
     kept = [len(ctx.debug_candidates(0, l)) for l in range(8)]
-    os.environ["VO_FAST_RAISE"] = "0"
+    ctx.set_option("fast_raise", 0)
     ctx.orb_detect(img, 2000)
     full = [len(ctx.debug_candidates(0, l)) for l in range(8)]
     print("image", k, "thr", thr.tolist(), "redo", redo.tolist(), "candidates", kept, "of", full, flush=True)

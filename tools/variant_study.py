@@ -70,13 +70,14 @@ for kind, a, b, nf in sets:
         op = O.estimate_motion(p1, p2, K)
         res[name] = (og, oE, oit, op)
         if ctx is not None:
-            os.environ["VO_FIVE_POINT_LITERAL"] = "1" if lit else "0"
+            ctx.set_option("five_point_literal", int(lit))
             gg, gE, gm, git, _ = ctx.find_essential(p1, p2, K)
             s = 1.0 if np.sum(gE * oE) > 0 else -1.0
             same = gg == og and git == oit and np.max(np.abs(gE - s * oE)) < (1e-8 if not lit else 1e-5)
             agree[name] += bool(same)
     O.set_variant(False, False)
-    os.environ["VO_FIVE_POINT_LITERAL"] = "0"
+    if ctx is not None:
+        ctx.set_option("five_point_literal", 0)
     (g0, E0, it0, p0), (g1, E1, it1, p1_) = res["default"], res["literal"]
     s = 1.0 if np.sum(E0 * E1) > 0 else -1.0
     changed_model += bool(np.max(np.abs(E0 - s * E1)) > 1e-6)

@@ -22,14 +22,17 @@ PAIR_DTYPE = np.dtype(
 )
 
 EXPORTS = [
-    "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
-    "vo_kernel_time_ms", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
-    "vo_hamming_knn2_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
+    "vo_device_count", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_stream", "vo_sync", "vo_set_timing",
+    "vo_kernel_time_ms", "vo_ctx_set_option", "vo_ctx_get_option", "vo_orb_detect", "vo_orb_detect_batch_dev", "vo_hamming_knn2",
+    "vo_hamming_knn2_dev", "vo_hamming_knn2_multi", "vo_hamming_knn2_multi_dev", "vo_match_ratio", "vo_match_ratio_static", "vo_estimate_motion", "vo_find_essential",
     "vo_match_images", "vo_pipeline_pairs_dev", "vo_pipeline_sequence_dev", "vo_pipeline_ticket", "vo_pipeline_wait", "vo_pipeline_sequence", "vo_pipeline_sequence_multi", "vo_block_range", "vo_debug_level", "vo_debug_candidates", "vo_debug_fast_stats", "vo_debug_fast_thresholds", "vo_debug_five_point",
 ]
 
 TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result.status bits (VO_TRUNC_*)
 WAIT_INPUTS, WAIT_RESULTS = 1, 2                                 # vo_pipeline_wait (VO_WAIT_*)
+# vo_ctx_set_option / vo_ctx_get_option (VO_OPT_*)
+OPTIONS = {"five_point_literal": 0, "fast_raise": 1, "knn_mode": 2, "knn_waves": 3, "knn_queries_per_lane": 4,
+           "second_chart": 5, "knn_train_split": 6}
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac",
             "ransac_solve", "ransac_score"]          # the last two split the RANSAC chain per round
 T_TOP = T_GROUPS[:8]
@@ -71,10 +74,14 @@ def load():
     lib.vo_set_timing.argtypes = [vp, i]
     lib.vo_kernel_time_ms.argtypes = [vp, i, C.POINTER(i)]
     lib.vo_kernel_time_ms.restype = f
+    lib.vo_ctx_set_option.argtypes = [vp, i, i]
+    lib.vo_ctx_get_option.argtypes = [vp, i, C.POINTER(i)]
     lib.vo_orb_detect.argtypes = [vp, vp, i, i, i, i, vp, vp, i, C.POINTER(i)]
     lib.vo_orb_detect_batch_dev.argtypes = [vp, vp, i, i, i, i, sz, i, vp, vp, i, vp]
     lib.vo_hamming_knn2.argtypes = [vp, vp, i, vp, i, vp, vp]
     lib.vo_hamming_knn2_dev.argtypes = [vp, vp, i, vp, i, vp, vp]
+    lib.vo_hamming_knn2_multi.argtypes = [vp, i, vp, i, vp, i, vp, vp]
+    lib.vo_hamming_knn2_multi_dev.argtypes = [vp, i, vp, i, vp, i, vp, vp]
     lib.vo_match_ratio.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, C.POINTER(i)]
     lib.vo_match_ratio_static.argtypes = [vp, vp, i, vp, i, f, vp, vp, vp, vp]
     lib.vo_estimate_motion.argtypes = [vp, vp, vp, i, vp, d, d, i, vp, vp, C.POINTER(i), C.POINTER(i), vp]
@@ -122,7 +129,9 @@ class Context:
         except Exception:
             pass
 
-    def _check(self, rc, what):
+    def _check(self, rc, what, allow_truncated=False):
+        if rc == 3 and allow_truncated:   # VO_ERR_CAPACITY from a host-buffer call: the outputs are still written
+            return
         if rc != 0:
             raise VoError(f"{what} failed (code {rc}): {self.lib.vo_last_error(self.h).decode()}")
 
@@ -143,6 +152,15 @@ class Context:
         self._check(self.lib.vo_pipeline_wait(self.h, int(ticket), (WAIT_INPUTS if inputs else 0) | (WAIT_RESULTS if results else 0)),
                     "vo_pipeline_wait")
 
+    def set_option(self, name, value):
+        """Sets one of the per-context switches (OPTIONS; include/vo_hip.h VO_OPT_*)."""
+        self._check(self.lib.vo_ctx_set_option(self.h, OPTIONS[name], int(value)), "vo_ctx_set_option")
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._check(self.lib.vo_ctx_get_option(self.h, OPTIONS[name], C.byref(v)), "vo_ctx_get_option")
+        return v.value
+
     def set_timing(self, on=True, groups=None):
         """Brackets the launches of the named kernel groups (default: all) with HIP events."""
         mask = 0
@@ -157,7 +175,7 @@ class Context:
         return ms, n.value
 
     # ---- host-buffer entry points ------------------------------------------------
-    def orb_detect(self, img, max_features=2000, want_desc=True, cap=None):
+    def orb_detect(self, img, max_features=2000, want_desc=True, cap=None, allow_truncated=False):
         if img is None or img.size == 0:
             n = C.c_int(-1)
             self._check(self.lib.vo_orb_detect(self.h, None, 0, 0, 0, max_features, None, None, 1, C.byref(n)),
@@ -170,7 +188,7 @@ class Context:
         desc = np.zeros((cap, 32), np.uint8) if want_desc else None
         n = C.c_int()
         self._check(self.lib.vo_orb_detect(self.h, _p(img), rows, cols, img.strides[0], int(max_features), _p(kps),
-                                           _p(desc), cap, C.byref(n)), "vo_orb_detect")
+                                           _p(desc), cap, C.byref(n)), "vo_orb_detect", allow_truncated)
         return kps[: n.value].copy(), (desc[: n.value].copy() if want_desc else None)
 
     def debug_level(self, image, level, blurred=False):
@@ -221,7 +239,7 @@ class Context:
                                             _p(d), C.byref(m)), "vo_match_ratio")
         return qi[: m.value].copy(), ti[: m.value].copy(), d[: m.value].copy()
 
-    def match_images(self, img1, img2, max_features=2000, ratio=0.75):
+    def match_images(self, img1, img2, max_features=2000, ratio=0.75, allow_truncated=False):
         """match_images_orb for one pair of host images: (kps1, kps2, query_idx, train_idx, distance)."""
         img1 = np.ascontiguousarray(img1, np.uint8)
         img2 = np.ascontiguousarray(img2, np.uint8)
@@ -238,7 +256,7 @@ class Context:
         n1, n2, m = C.c_int(), C.c_int(), C.c_int()
         self._check(self.lib.vo_match_images(self.h, _p(img1), _p(img2), rows, cols, img1.strides[0], int(max_features),
                                              float(ratio), _p(k1), C.byref(n1), _p(k2), C.byref(n2), cap, _p(qi),
-                                             _p(ti), _p(d), C.byref(m)), "vo_match_images")
+                                             _p(ti), _p(d), C.byref(m)), "vo_match_images", allow_truncated)
         return (k1[: n1.value].copy(), k2[: n2.value].copy(), qi[: m.value].copy(), ti[: m.value].copy(),
                 d[: m.value].copy())
 
@@ -341,3 +359,27 @@ def pipeline_sequence_multi(contexts, frames, max_features, K, ratio=0.75, thres
                                            _p(Kd), threshold, confidence, fixed_iters, _p(out))
     contexts[0]._check(rc, "vo_pipeline_sequence_multi")
     return out
+
+
+def hamming_knn2_multi(contexts, q, t):
+    """vo_hamming_knn2 over several contexts (one per GPU): query rows sharded in contiguous blocks,
+    train set replicated, host arrays in and out."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.full((len(q), 2), -7, np.int32)
+    dist = np.full((len(q), 2), -7, np.int32)
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = load().vo_hamming_knn2_multi(arr, len(contexts), _p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    contexts[0]._check(rc, "vo_hamming_knn2_multi")
+    return idx, dist
+
+
+def hamming_knn2_multi_dev(contexts, d_q_blocks, nq, d_t_copies, nt, d_idx2, d_dist2):
+    """Device-resident form: d_q_blocks[k] / d_t_copies[k] are device addresses on context k's GPU,
+    the tables live on context 0's GPU.  Only enqueues: sync every context afterwards."""
+    n = len(contexts)
+    arr = (C.c_void_p * n)(*[c.h for c in contexts])
+    qs = (C.c_void_p * n)(*d_q_blocks)
+    ts = (C.c_void_p * n)(*d_t_copies)
+    rc = load().vo_hamming_knn2_multi_dev(arr, n, qs, int(nq), ts, int(nt), d_idx2, d_dist2)
+    contexts[0]._check(rc, "vo_hamming_knn2_multi_dev")

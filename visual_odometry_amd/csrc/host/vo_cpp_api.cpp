@@ -55,11 +55,14 @@ vo_ctx* ctx() {
     return t.c;
 }
 
+// VO_ERR_CAPACITY from a host-buffer call means that a keypoint list was cut at a table's end
+// (thousands of tied scores): the outputs are still written, so the caller gets them - the
+// reference returns its (larger) lists in that case too - and the message is kept in last_error().
 bool ok(int rc) {
     auto& t = tls();
     if (rc == VO_OK) return true;
     t.err = t.c ? vo_last_error(t.c) : "no GPU context";
-    return false;
+    return rc == VO_ERR_CAPACITY;
 }
 
 static_assert(sizeof(vo_keypoint) == 28);

@@ -255,8 +255,11 @@ struct Decoder {
         int s = decode_symbol(br, hd);
         if (s < 0 || s > 11) return false;
         if (s) c.pred += extend(br.bits(s), s);
+        // a DC value of an 8-bit image fits 12 bits; a predictor that a hostile stream has driven
+        // out of 16 would overflow the product below
+        if (c.pred < -32768 || c.pred > 32767) return false;
         uint16_t const* q = quant[c.tq];
-        coef[0] = c.pred * q[0];
+        coef[0] = c.pred * (int32_t)q[0];
         for (int k = 1; k < 64;) {
             int const rs = decode_symbol(br, ha);
             if (rs < 0) return false;
@@ -280,7 +283,7 @@ struct Decoder {
     // One scan; `p` is the first byte after the scan header.  Returns the position of the marker
     // that ends the entropy-coded data, or 0 on error.
     size_t decode_scan(size_t p, int ns, int const* index) {
-        BitReader br{&f[p], f.data() + f.size()};
+        BitReader br{f.data() + p, f.data() + f.size()};   // (p may equal f.size(): a file that ends behind the scan header)
         for (int i = 0; i < ns; ++i) comp[index[i]].pred = 0;
         size_t mcux, mcuy;
         if (ns == 1) {   // non-interleaved: the component's own block grid

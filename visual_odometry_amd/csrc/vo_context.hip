@@ -1,5 +1,7 @@
 // Context management for libvo_hip.so: device selection, the stream every
 // kernel is enqueued on, grow-only device buffers and the last-error string.
+#include <cstdlib>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -89,6 +91,10 @@ int take_truncation(vo_ctx* c, const char* who) {
     VO_HIP(c, hipMemcpy(&bits, c->flags.p, 4, hipMemcpyDeviceToHost));
     if (!bits) return VO_OK;
     VO_HIP(c, hipMemset(c->flags.p, 0, 4));
+    return truncation_error(c, who, bits);
+}
+
+int truncation_error(vo_ctx* c, const char* who, uint32_t bits) {
     std::string what;
     if (bits & VO_TRUNC_SCORE_LIST) what += " [FAST-score selection: ties at the 2 x quota cut exceed the selection table]";
     if (bits & VO_TRUNC_KEYPOINT_LIST) what += " [Harris selection: ties at the quota cut exceed a level's keypoint table]";
@@ -112,6 +118,57 @@ static bool create_ticket_events(vo_ctx* c) {
     return true;
 }
 
+// Default of an option: the integer in the named environment variable if it is set and admissible.
+static bool option_admits(int option, int v) {
+    switch (option) {
+        case VO_OPT_FIVE_POINT_LITERAL: return v == 0 || v == 1;
+        case VO_OPT_FAST_RAISE: return v >= -1 && v <= 1;
+        case VO_OPT_KNN_MODE: return v >= -1 && v <= 1;
+        case VO_OPT_KNN_WAVES: return v == 0 || v == 1 || v == 4 || v == 8 || v == 16;
+        case VO_OPT_KNN_QUERIES_PER_LANE: return v == 0 || v == 1 || v == 2 || v == 4;
+        case VO_OPT_SECOND_CHART: return v == 0 || v == 1;
+        case VO_OPT_KNN_TRAIN_SPLIT: return v >= 0 && v <= 64;
+        default: return false;
+    }
+}
+
+static void option_defaults(vo_ctx* c) {
+    static const struct { int option; const char* env; int dflt; } table[] = {
+        {VO_OPT_FIVE_POINT_LITERAL, "VO_FIVE_POINT_LITERAL", 0}, {VO_OPT_FAST_RAISE, "VO_FAST_RAISE", -1},
+        {VO_OPT_KNN_MODE, "VO_KNN_MODE", -1},                     {VO_OPT_KNN_WAVES, "VO_KNN_NW", 0},
+        {VO_OPT_KNN_QUERIES_PER_LANE, "VO_KNN_QPL", 0},           {VO_OPT_SECOND_CHART, "VO_SECOND_CHART", 1},
+        {VO_OPT_KNN_TRAIN_SPLIT, "VO_KNN_SPLIT", 0}};
+    for (const auto& t : table) {
+        int v = t.dflt;
+        if (const char* e = getenv(t.env)) {
+            char* end = nullptr;
+            const long x = strtol(e, &end, 10);
+            if (end != e && option_admits(t.option, (int)x)) v = (int)x;
+        }
+        c->opt[t.option] = v;
+    }
+}
+
+extern "C" int vo_ctx_set_option(vo_ctx* c, int option, int value) {
+    if (!c) return VO_ERR_INVALID;
+    if (option < 0 || option >= VO_OPT_COUNT || !option_admits(option, value))
+        return fail(c, VO_ERR_INVALID, "vo_ctx_set_option: option " + std::to_string(option) + " does not take the value " +
+                                           std::to_string(value));
+    c->opt[option] = value;
+    return VO_OK;
+}
+
+extern "C" int vo_ctx_get_option(const vo_ctx* c, int option, int* value) {
+    if (!c || !value || option < 0 || option >= VO_OPT_COUNT) return VO_ERR_INVALID;
+    *value = c->opt[option];
+    return VO_OK;
+}
+
+extern "C" int vo_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (!out) return VO_ERR_INVALID;
     *out = nullptr;
@@ -121,6 +178,7 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return VO_ERR_HIP;
     vo_ctx* c = new vo_ctx();
     c->device = device;
+    option_defaults(c);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess ||
@@ -158,7 +216,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* c) {
     DevBuf* bufs[] = {&c->fast_thr, &c->fast_redo,
                       &c->tab,      &c->pyr,      &c->blur,    &c->cand,    &c->cand_cnt, &c->kp_x,     &c->kp_y,
                       &c->kp_resp,  &c->sel_keys, &c->sel_resp, &c->sel_cnt, &c->kp_cnt,  &c->flags,   &c->img_status, &c->fast_stats, &c->st_img,   &c->st_kps,   &c->st_desc,
-                      &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->st_down,  &c->m_top2,   &c->m_qidx,
+                      &c->st_cnt,   &c->st_q,     &c->st_t,    &c->st_idx,  &c->st_dist,  &c->st_down,  &c->m_top2, &c->k_part,   &c->m_qidx,
                       &c->m_tidx,   &c->m_dist,   &c->m_p1,    &c->m_p2,    &c->m_cnt,    &c->r_state,  &c->r_samples,
                       &c->r_models, &c->r_nmodels, &c->r_models2, &c->r_nmodels2, &c->r_retry, &c->r_roots, &c->r_nroots, &c->r_counts, &c->r_best, &c->r_mask,  &c->r_pts,    &c->r_ptsf, &c->r_res,
                       &c->p_kps,    &c->p_desc,   &c->p_cnt};

@@ -124,6 +124,7 @@ struct vo_ctx {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fast0 = nullptr, ev_blur = nullptr;
     std::string err;
+    int opt[VO_OPT_COUNT] = {};   // VO_OPT_* values (defaults set by vo_ctx_create)
     unsigned timing = 0;   // bit g: kernel group g is bracketed by events
     std::vector<hipEvent_t> ev_pool;                 // every event ever created (reused after a reset)
     size_t ev_used = 0;
@@ -138,6 +139,10 @@ struct vo_ctx {
     // to truncate a list ORs into and that only take_truncation() clears; `img_status` holds one
     // word per image of the most recent detection call.
     vo::DevBuf flags, img_status;
+    // Word of `flags` the detection kernels OR into: 0, the sticky word, for device-resident calls
+    // (which can only report through vo_sync); 16, a word nobody reads, for host-buffer calls,
+    // which wait for their own result and report from their images' status words instead.
+    int flags_word = 0;
     vo::DevBuf fast_stats;                // four 64-bit scene counters (vo_debug_fast_stats)
     vo::DevBuf fast_thr, fast_redo;       // raised FAST threshold per (image, level); the two launch groups' redo lists
     bool fast_raised = false;             // the most recent detection call ran with raised thresholds
@@ -151,6 +156,7 @@ struct vo_ctx {
     size_t h_pin_bytes = 0;
     // matching / RANSAC workspace
     vo::DevBuf m_top2, m_qidx, m_tidx, m_dist, m_p1, m_p2, m_cnt;
+    vo::DevBuf k_part;   // per-chunk two best of a Hamming search split over the train set (main stream only)
     vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_roots, r_nroots, r_counts, r_best, r_mask, r_pts, r_ptsf, r_res;
     // pipeline workspace
     vo::DevBuf p_kps, p_desc, p_cnt;
@@ -173,6 +179,8 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes);
 // Reads and clears the context's sticky truncation word (the streams must have been waited for):
 // VO_OK if it was zero, else VO_ERR_CAPACITY with the stages named in the error message.
 int take_truncation(vo_ctx* c, const char* who);
+// VO_ERR_CAPACITY with the stages of the VO_TRUNC_* bits named in the error message.
+int truncation_error(vo_ctx* c, const char* who, uint32_t bits);
 
 #define VO_HIP(c, call)                                                                   \
     do {                                                                                  \

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "vo_internal.h"
 
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __re
                                                          int cnt_stride, int nq_max, size_t q_stride,
                                                          const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr,
                                                          int nt_max, size_t t_stride, int32_t* __restrict__ idx2,
-                                                         int32_t* __restrict__ dist2) {
+                                                         int32_t* __restrict__ dist2, int rows_per_z,
+                                                         unsigned long long* __restrict__ part_out) {
     __shared__ uint4 rows[NW][128];   // per wavefront: 64 rows of two uint4
     __shared__ unsigned long long part[NW][64][2];
 
@@ -213,9 +216,13 @@ __global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __re
     }
     unsigned long long best0 = ~0ull, best1 = ~0ull;
     uint4* my_rows = rows[wave];
+    // blockIdx.z: this workgroup's chunk of the train set (one chunk, rows_per_z = INT_MAX, unless
+    // the search was split; see knn2_merge_kernel)
+    const int t_lo = min((int)blockIdx.z * (long long)rows_per_z, (long long)nt);
+    const int t_hi = (int)min((long long)nt, (long long)t_lo + rows_per_z);
 
-    for (int cbase = 0; cbase < nt; cbase += 65536) {
-        const int cn = min(nt - cbase, 65536);
+    for (int cbase = t_lo; cbase < t_hi; cbase += 65536) {
+        const int cn = min(t_hi - cbase, 65536);
         uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, thr = 0xFFFFu;
         const uint4* tcb = reinterpret_cast<const uint4*>(tb + (size_t)cbase * 32);
         auto fetch = [&](int first, uint4* a, uint4* c) {   // row first + lane of the chunk (clamped)
@@ -298,6 +305,12 @@ __global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __re
             unsigned long long a0 = part[0][tid][0], a1 = part[0][tid][1];
 #pragma unroll
             for (int w = 1; w < NW; ++w) merge2(a0, a1, part[w][tid][0], part[w][tid][1]);
+            if (part_out) {   // split search: the chunk's two best as keys, merged by knn2_merge_kernel
+                const size_t po = (((size_t)b * gridDim.z + blockIdx.z) * nq_max + qi) * 2;
+                part_out[po] = a0;
+                part_out[po + 1] = a1;
+                return;
+            }
             const size_t o = ((size_t)b * nq_max + qi) * 2;
             idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
             idx2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(uint32_t)a1;
@@ -305,6 +318,30 @@ __global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __re
             dist2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(a1 >> 32);
         }
     }
+}
+
+// A search with few query rows (one shard of a large match: 8 192 rows are 128 workgroups on 256
+// compute units) is split over the train set as well: grid.z chunks of rows_per_z train rows, each
+// workgroup leaving its chunk's two best per query as keys (distance << 32 | train row).  The keys
+// order by distance, then by row, which is what an ascending scan with a strict '<' keeps: the two
+// smallest keys over all chunks are the result of the unsplit search, ties included.
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const unsigned long long* __restrict__ part,
+                                                         const int32_t* __restrict__ nq_arr, int cnt_stride, int nq_max,
+                                                         int split, int32_t* __restrict__ idx2,
+                                                         int32_t* __restrict__ dist2) {
+    const int b = blockIdx.y, qi = blockIdx.x * 256 + threadIdx.x;
+    const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
+    if (qi >= nq) return;
+    unsigned long long a0 = ~0ull, a1 = ~0ull;
+    for (int z = 0; z < split; ++z) {
+        const size_t po = (((size_t)b * split + z) * nq_max + qi) * 2;
+        merge2(a0, a1, part[po], part[po + 1]);
+    }
+    const size_t o = ((size_t)b * nq_max + qi) * 2;
+    idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
+    idx2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(uint32_t)a1;
+    dist2[o] = a0 == ~0ull ? -1 : (int32_t)(a0 >> 32);
+    dist2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(a1 >> 32);
 }
 
 // Lowe ratio test and ordered compaction (query order), one workgroup per
@@ -379,17 +416,13 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
         qpl = 4;
         while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
     }
-    if (const char* e = getenv("VO_KNN_QPL")) {   // tuning aid
-        int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) qpl = v;
-    }
+    if (c->opt[VO_OPT_KNN_QUERIES_PER_LANE] > 0) qpl = c->opt[VO_OPT_KNN_QUERIES_PER_LANE];   // tuning aid
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
     hipStream_t s = c->stream;
     t_begin(c, VO_T_KNN2);
-    // One query per lane: the variant with the train rows in vector registers.  VO_KNN_MODE=0
-    // selects the scalar-operand kernel instead, 4 / 8 / 16 a workgroup size (tuning aids).
-    const char* mode_env = getenv("VO_KNN_MODE");
-    const int mode = mode_env ? atoi(mode_env) : 1;
+    // One query per lane: the variant with the train rows in vector registers.  VO_OPT_KNN_MODE = 0
+    // selects the scalar-operand kernel instead (tuning aid).
+    const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 1 : c->opt[VO_OPT_KNN_MODE];
     if (qpl == 1 && mode >= 1) {
         // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
         // still has several to switch between.  Many (a batch of some hundred pairs): one
@@ -401,14 +434,33 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
         const int nq_live = nq_typical > 0 ? std::min(nq_typical, nq_max) : nq_max;
         const long long live = (long long)((nq_live + 63) / 64) * batch;
         int nw = live >= 12 * 1024 ? 1 : wgs * 4 >= 8 * 1024 ? 4 : wgs * 8 >= 8 * 1024 ? 8 : 16;
-        if (mode == 4 || mode == 8 || mode == 16) nw = mode;
-        if (const char* e = getenv("VO_KNN_NW")) {   // tuning aid
-            const int v = atoi(e);
-            if (v == 1 || v == 4 || v == 8 || v == 16) nw = v;
+        // Fewer than four workgroups per compute unit even so (a shard of a large match): the train
+        // set is split as well, into chunks of whole 64-row blocks with at least 128 rows for each
+        // wavefront of a workgroup, and a second kernel merges the chunks' results.
+        int split = 1;
+        // (only where the train count is known on the host and large: the pipeline's per-pair
+        // searches pass capacities and are batched instead)
+        if (wgs < 1024 && !d_nt && nt_max >= 8192) {
+            nw = 8;
+            split = (int)std::min<long long>({64, (1024 + wgs - 1) / wgs, nt_max / 1024});
+        }
+        if (c->opt[VO_OPT_KNN_WAVES] > 0) nw = c->opt[VO_OPT_KNN_WAVES];   // tuning aids
+        if (c->opt[VO_OPT_KNN_TRAIN_SPLIT] > 0) split = c->opt[VO_OPT_KNN_TRAIN_SPLIT];
+        split = std::max(1, std::min(split, (nt_max + 63) / 64));
+        int rows_per_z = 0x7FFFFFFF;
+        unsigned long long* part = nullptr;
+        if (split > 1) {
+            rows_per_z = (((nt_max + split - 1) / split) + 63) & ~63;
+            split = (nt_max + rows_per_z - 1) / rows_per_z;
+        }
+        if (split > 1) {
+            if (int rc = ensure(c, c->k_part, (size_t)batch * split * nq_max * 16)) return rc;
+            part = (unsigned long long*)c->k_part.p;
+            grid.z = split;
         }
 #define VO_KNN_LAUNCH(NW)                                                                                              \
     hipLaunchKernelGGL(knn2_bcast_kernel<NW>, grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, \
-                       d_nt, nt_max, t_stride, d_idx2, d_dist2)
+                       d_nt, nt_max, t_stride, d_idx2, d_dist2, rows_per_z, part)
         switch (nw) {
             case 1: VO_KNN_LAUNCH(1); break;
             case 4: VO_KNN_LAUNCH(4); break;
@@ -416,6 +468,9 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
             default: VO_KNN_LAUNCH(16); break;
         }
 #undef VO_KNN_LAUNCH
+        if (split > 1)
+            hipLaunchKernelGGL(knn2_merge_kernel, dim3((nq_max + 255) / 256, batch), dim3(256), 0, s,
+                               (const unsigned long long*)part, d_nq, cnt_stride, nq_max, split, d_idx2, d_dist2);
     } else if (qpl == 4)
         hipLaunchKernelGGL(knn2_kernel<4>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);
@@ -501,7 +556,7 @@ extern "C" int vo_match_ratio_static(vo_ctx* c, const uint8_t* d_q, int nq, cons
         // every size this entry point admits
         dim3 grid((nq + 63) / 64, 1);
         hipLaunchKernelGGL(knn2_bcast_kernel<4>, grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
-                           (const int32_t*)nullptr, nt, (size_t)0, idx2, dist2);
+                           (const int32_t*)nullptr, nt, (size_t)0, idx2, dist2, 0x7FFFFFFF, (unsigned long long*)nullptr);
     }
     hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)idx2, (const int32_t*)dist2,
                        (const int32_t*)nullptr, 1, nq, ratio, (const vo_keypoint*)nullptr, (const vo_keypoint*)nullptr,
@@ -581,5 +636,92 @@ extern "C" int vo_match_ratio(vo_ctx* c, const uint8_t* q, int nq, const uint8_t
         VO_HIP(c, hipStreamSynchronize(c->stream));
     }
     *n_out = m;
+    return VO_OK;
+}
+
+// One large match over several GPUs of one node: the distance matrix is sharded by query rows
+// (contiguous blocks, vo_block_range), the train set is replicated, and a query's two nearest
+// rows are complete inside its shard, so no reduction follows - only the shards' result rows are
+// brought together.  Host-buffer form: context k, on a host thread of its own, uploads its query
+// block and the train set, searches, and downloads straight into rows [begin, end) of the
+// caller's tables.
+extern "C" int vo_hamming_knn2_multi(vo_ctx* const* ctxs, int n_ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                     int32_t* idx2, int32_t* dist2) {
+    if (!ctxs || n_ctx <= 0) return VO_ERR_INVALID;
+    for (int k = 0; k < n_ctx; ++k)
+        if (!ctxs[k]) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx2 || !dist2)) || (nt > 0 && !t))
+        return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi: bad argument");
+    for (int a = 0; a < n_ctx; ++a)
+        for (int b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a] == ctxs[b])
+                return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi: a context is listed twice (contexts are not thread-safe)");
+    std::vector<int> rc((size_t)n_ctx, VO_OK);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n_ctx; ++k) {
+        int b = 0, e = 0;
+        vo_block_range(nq, k, n_ctx, &b, &e);
+        if (e <= b) continue;   // more contexts than query rows
+        workers.emplace_back([=, &rc] {
+            rc[(size_t)k] = vo_hamming_knn2(ctxs[k], q + (size_t)b * 32, e - b, t, nt, idx2 + (size_t)b * 2, dist2 + (size_t)b * 2);
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int k = 0; k < n_ctx; ++k)
+        if (rc[(size_t)k] != VO_OK) {
+            if (k != 0) ctxs[0]->err = "context " + std::to_string(k) + ": " + ctxs[k]->err;
+            return rc[(size_t)k];
+        }
+    return VO_OK;
+}
+
+// Device-resident form.  d_q[k]: the query rows of block k (vo_block_range(nq, k, n_ctx)) on
+// context k's GPU; d_t[k]: the whole train set on that GPU; d_idx2 / d_dist2: the full nq x 2
+// tables on context 0's GPU.  Context k searches into a table of its own and sends its rows to
+// their place in context 0's tables with one peer copy per table on its own stream (over xGMI
+// between two GPUs; an ordinary device copy when both contexts sit on one GPU) - the path's one
+// exchange step.  Everything is enqueued from the calling thread; the tables are complete once
+// vo_sync() has returned for every context.
+extern "C" int vo_hamming_knn2_multi_dev(vo_ctx* const* ctxs, int n_ctx, const uint8_t* const* d_q, int nq,
+                                         const uint8_t* const* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2) {
+    if (!ctxs || n_ctx <= 0) return VO_ERR_INVALID;
+    for (int k = 0; k < n_ctx; ++k)
+        if (!ctxs[k]) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || !d_q || !d_t || (nq > 0 && (!d_idx2 || !d_dist2)))
+        return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi_dev: bad argument");
+    for (int a = 0; a < n_ctx; ++a)
+        for (int b = a + 1; b < n_ctx; ++b)
+            if (ctxs[a] == ctxs[b])
+                return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi_dev: a context is listed twice");
+    for (int k = 0; k < n_ctx; ++k) {
+        vo_ctx* c = ctxs[k];
+        int b = 0, e = 0;
+        vo_block_range(nq, k, n_ctx, &b, &e);
+        const int rows = e - b;
+        if (rows <= 0) continue;
+        if (!d_q[k] || (nt > 0 && !d_t[k])) return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi_dev: a block's pointer is NULL");
+        if (((uintptr_t)d_q[k] | (uintptr_t)d_t[k]) & 15)
+            return fail(ctxs[0], VO_ERR_INVALID, "vo_hamming_knn2_multi_dev: descriptor arrays must be 16-byte aligned");
+        auto relay = [&](int code) {
+            if (k != 0) ctxs[0]->err = "context " + std::to_string(k) + ": " + c->err;
+            return code;
+        };
+        if (hipSetDevice(c->device) != hipSuccess) return relay(fail(c, VO_ERR_HIP, "hipSetDevice failed"));
+        int32_t *li = d_idx2 + (size_t)b * 2, *ld = d_dist2 + (size_t)b * 2;
+        if (k != 0) {   // context 0 writes its rows in place
+            int rc;
+            if ((rc = ensure(c, c->st_idx, (size_t)rows * 8)) || (rc = ensure(c, c->st_dist, (size_t)rows * 8))) return relay(rc);
+            if ((rc = join_side(c))) return relay(rc);   // a pipeline call's tail may still read these tables
+            li = (int32_t*)c->st_idx.p;
+            ld = (int32_t*)c->st_dist.p;
+        }
+        if (int rc = knn2_launch(c, d_q[k], nullptr, 1, rows, 0, d_t[k], nullptr, nt, 0, 1, li, ld)) return relay(rc);
+        if (k != 0) {
+            const hipError_t e1 = hipMemcpyPeerAsync(d_idx2 + (size_t)b * 2, ctxs[0]->device, li, c->device, (size_t)rows * 8, c->stream);
+            const hipError_t e2 = hipMemcpyPeerAsync(d_dist2 + (size_t)b * 2, ctxs[0]->device, ld, c->device, (size_t)rows * 8, c->stream);
+            if (e1 != hipSuccess || e2 != hipSuccess)
+                return relay(fail(c, VO_ERR_HIP, std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2)));
+        }
+    }
     return VO_OK;
 }

@@ -1703,10 +1703,10 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     };
     // Raised thresholds (fast_raise_kernel) pay on batches: the group becomes five launches, three
     // of them FAST passes, which a call on a few images only feels as launch latency.  The scene
-    // counters describe the plain run, so they switch it off as well.  VO_FAST_RAISE=0 / 1
+    // counters describe the plain run, so they switch it off as well.  VO_OPT_FAST_RAISE = 0 / 1
     // switches it off / on whatever the batch (measurement and test aid).
     bool raise = (size_t)N * (size_t)g.fast_tiles >= 4096 && !c->fast_stats_on;
-    if (const char* e = getenv("VO_FAST_RAISE")) raise = e[0] == '1' && !c->fast_stats_on;
+    if (c->opt[VO_OPT_FAST_RAISE] >= 0) raise = c->opt[VO_OPT_FAST_RAISE] == 1 && !c->fast_stats_on;
     c->fast_raised = raise;
     if (raise) VO_HIP(c, hipMemsetAsync(c->fast_redo.p, 0, c->fast_redo.bytes, s));   // (before the fork below)
     // one launch group: tiles [first, first + count) of the table, the first `ns` of them sampled,
@@ -1795,13 +1795,13 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     do {                                                                                                             \
         hipLaunchKernelGGL(select_a_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g, (const uint32_t*)c->cand.p,  \
                            (const uint32_t*)c->cand_cnt.p, (uint32_t*)c->sel_keys.p, (uint32_t*)c->sel_cnt.p,        \
-                           (uint32_t*)c->flags.p, c->img_status_cur);                                       \
+                           (uint32_t*)c->flags.p + c->flags_word, c->img_status_cur);                                       \
         hipLaunchKernelGGL(harris_kernel, dim3(xcd_grid((uint32_t)hb.first[kLevels] * N)), dim3(256), 0, s, g, CAPV, hb, d_imgs, \
                            pyr, (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p, (float*)c->sel_resp.p); \
         hipLaunchKernelGGL(select_b_kernel<CAPV>, dim3(N, kLevels), dim3(512), 0, s, g,                              \
                            (const uint32_t*)c->sel_keys.p, (const uint32_t*)c->sel_cnt.p,                            \
                            (const float*)c->sel_resp.p, (uint16_t*)c->kp_x.p, (uint16_t*)c->kp_y.p,                  \
-                           (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p,                      \
+                           (float*)c->kp_resp.p, (uint32_t*)c->kp_cnt.p, (uint32_t*)c->flags.p + c->flags_word,                      \
                            c->img_status_cur);                                                              \
     } while (0)
     if (g.sel_cap == 2048) VO_SELECT(2048);
@@ -1821,7 +1821,7 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
     const int dbx = std::max((g.max_features + 31) / 32, 1);   // about four keypoint pairs per wavefront
     hipLaunchKernelGGL(orient_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx, d_imgs, pyr,
                        (const uint16_t*)c->kp_x.p, (const uint16_t*)c->kp_y.p, (const float*)c->kp_resp.p,
-                       (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p,
+                       (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p + c->flags_word,
                        c->img_status_cur);
     if (blur_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     if (d_desc)
@@ -1858,20 +1858,26 @@ extern "C" int vo_orb_detect(vo_ctx* c, const uint8_t* img, int rows, int cols, 
         return fail(c, VO_ERR_INVALID, "vo_orb_detect: bad argument");
     VO_HIP(c, hipSetDevice(c->device));
     size_t bytes = (size_t)rows * step;
+    // (the last row ends after `cols` bytes: a sub-image's buffer may end there)
+    const size_t valid = (size_t)(rows - 1) * step + cols;
     int rc;
     if ((rc = ensure(c, c->st_img, bytes))) return rc;
     if ((rc = ensure(c, c->st_kps, (size_t)cap * sizeof(vo_keypoint)))) return rc;
     if ((rc = ensure(c, c->st_desc, (size_t)cap * 32))) return rc;
     if ((rc = ensure(c, c->st_cnt, 64))) return rc;
-    VO_HIP(c, hipMemcpyAsync(c->st_img.p, img, bytes, hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->st_img.p, img, valid, hipMemcpyHostToDevice, c->stream));
     if ((rc = orb_prepare(c, 1, rows, cols, step, bytes, max_features))) return rc;
-    if ((rc = orb_run(c, (const uint8_t*)c->st_img.p, (vo_keypoint*)c->st_kps.p,
-                      desc_out ? (uint8_t*)c->st_desc.p : nullptr, cap, (int32_t*)c->st_cnt.p)))
-        return rc;
+    c->flags_word = 16;   // this call reports from its own image's status word
+    rc = orb_run(c, (const uint8_t*)c->st_img.p, (vo_keypoint*)c->st_kps.p, desc_out ? (uint8_t*)c->st_desc.p : nullptr,
+                 cap, (int32_t*)c->st_cnt.p);
+    c->flags_word = 0;
+    if (rc) return rc;
     int32_t n = 0;
+    uint32_t status = 0;
     VO_HIP(c, hipMemcpyAsync(&n, c->st_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(&status, c->img_status_cur, 4, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    if ((rc = take_truncation(c, "vo_orb_detect"))) return rc;
+    n = std::min(n, cap);
     if (n > 0) {
         VO_HIP(c, hipMemcpyAsync(kps_out, c->st_kps.p, (size_t)n * sizeof(vo_keypoint), hipMemcpyDeviceToHost,
                                  c->stream));
@@ -1880,7 +1886,8 @@ extern "C" int vo_orb_detect(vo_ctx* c, const uint8_t* img, int rows, int cols, 
         VO_HIP(c, hipStreamSynchronize(c->stream));
     }
     *n_out = n;
-    return VO_OK;
+    // a truncated list is reported, but what was kept is still handed out
+    return status ? truncation_error(c, "vo_orb_detect", status) : VO_OK;
 }
 
 extern "C" int vo_debug_level(vo_ctx* c, int image, int level, int blurred, uint8_t* out, size_t out_bytes, int* w,

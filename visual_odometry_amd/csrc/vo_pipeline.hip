@@ -24,19 +24,42 @@ __global__ void fill_counts_kernel(vo_pair_result* __restrict__ res, const int32
     res[p].status = (int32_t)(img_status[pair_step * p] | img_status[pair_step * p + 1]);
 }
 
+// out[0] = OR of the n status words (n <= 64)
+__global__ void or_status_kernel(const uint32_t* __restrict__ status, int n, uint32_t* __restrict__ out) {
+    uint32_t v = (int)threadIdx.x < n ? status[threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
 }  // namespace vo
 
 using namespace vo;
 
 // Shared body: n_images frames, pair p = (p * pair_step, p * pair_step + 1).
+static int pipeline_body(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
+                         int step, size_t image_stride, int max_features, float ratio, const double K[4],
+                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results);
+
 static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
                         int step, size_t image_stride, int max_features, float ratio, const double K[4],
                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
     VO_HIP(c, hipSetDevice(c->device));
-    int rc;
     // this call's tail takes the tail set the call before the previous one used: it runs beside
-    // the previous call's tail (and behind the older one, in stream order)
+    // the previous call's tail (and behind the older one, in stream order).  A call that fails
+    // takes no ticket, so it gives the set back: tickets and tail sets stay in step (a ticket's
+    // parity names its tail stream, which vo_pipeline_wait relies on).
     c->swap_tail();
+    const int rc = pipeline_body(c, d_imgs, n_images, n_pairs, pair_step, rows, cols, step, image_stride, max_features,
+                                 ratio, K, threshold, confidence, fixed_iters, d_results);
+    if (rc != VO_OK) c->swap_tail();
+    return rc;
+}
+
+static int pipeline_body(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
+                         int step, size_t image_stride, int max_features, float ratio, const double K[4],
+                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
+    int rc;
     if ((rc = orb_prepare(c, n_images, rows, cols, step, image_stride, max_features))) return rc;
     const int cap = c->g.kp_stride;   // quota + slack of every level: the detector cannot return more
     if ((rc = ensure(c, c->p_kps, (size_t)n_images * cap * sizeof(vo_keypoint)))) return rc;
@@ -193,15 +216,20 @@ extern "C" int vo_match_images(vo_ctx* c, const uint8_t* img1, const uint8_t* im
     if ((rc = ensure(c, c->st_dist, (size_t)cap * 8))) return rc;
     if ((rc = join_side(c))) return rc;   // a pipeline call's tail may still use the staging and match buffers
     uint8_t* pin = (uint8_t*)c->h_pin;
-    std::memcpy(pin, img1, img_bytes);
-    std::memcpy(pin + img_bytes, img2, img_bytes);
+    // (the last row of an image ends after `cols` bytes: a sub-image's buffer may end there)
+    const size_t valid = (size_t)(rows - 1) * step + cols;
+    std::memcpy(pin, img1, valid);
+    std::memcpy(pin + img_bytes, img2, valid);
     VO_HIP(c, hipMemcpyAsync(c->st_img.p, pin, 2 * img_bytes, hipMemcpyHostToDevice, c->stream));
     if ((rc = orb_prepare(c, 2, rows, cols, step, img_bytes, max_features))) return rc;
     uint8_t* down = (uint8_t*)c->st_down.p;
     int32_t* d_cnt = (int32_t*)down;
     vo_keypoint* d_kps = (vo_keypoint*)(down + off_k1);
     uint8_t* d_desc = (uint8_t*)c->st_desc.p;
-    if ((rc = orb_run(c, (const uint8_t*)c->st_img.p, d_kps, d_desc, cap, d_cnt))) return rc;
+    c->flags_word = 16;   // this call reports from its own images' status words
+    rc = orb_run(c, (const uint8_t*)c->st_img.p, d_kps, d_desc, cap, d_cnt);
+    c->flags_word = 0;
+    if (rc) return rc;
     if ((rc = knn2_launch(c, d_desc, d_cnt, 1, cap, 0, d_desc + (size_t)cap * 32, d_cnt + 1, cap, 0, 1, (int32_t*)c->st_idx.p,
                           (int32_t*)c->st_dist.p, max_features)))
         return rc;
@@ -209,11 +237,14 @@ extern "C" int vo_match_images(vo_ctx* c, const uint8_t* img1, const uint8_t* im
                            nullptr, 0, (int32_t*)(down + off_q), (int32_t*)(down + off_t), (float*)(down + off_d), nullptr,
                            nullptr, d_cnt + 2, c->stream)))
         return rc;
+    // (the fourth word of the block's header takes the two images' truncation bits)
+    hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->img_status_cur, 2,
+                       (uint32_t*)(d_cnt + 3));
     VO_HIP(c, hipMemcpyAsync(pin, down, down_bytes, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    if ((rc = take_truncation(c, "vo_match_images"))) return rc;
     const int32_t* h_cnt = (const int32_t*)pin;
-    const int n1 = h_cnt[0], n2 = h_cnt[1], m = h_cnt[2];
+    const int n1 = std::min(h_cnt[0], cap), n2 = std::min(h_cnt[1], cap), m = std::min(h_cnt[2], cap);
+    const uint32_t status = (uint32_t)h_cnt[3];
     std::memcpy(kps1, pin + off_k1, (size_t)n1 * sizeof(vo_keypoint));
     std::memcpy(kps2, pin + off_k2, (size_t)n2 * sizeof(vo_keypoint));
     std::memcpy(query_idx, pin + off_q, (size_t)m * 4);
@@ -222,7 +253,8 @@ extern "C" int vo_match_images(vo_ctx* c, const uint8_t* img1, const uint8_t* im
     *n_kps1 = n1;
     *n_kps2 = n2;
     *n_matches = m;
-    return VO_OK;
+    // a truncated keypoint list is reported, but what was kept - and matched - is still handed out
+    return status ? truncation_error(c, "vo_match_images", status) : VO_OK;
 }
 
 // Contiguous block [begin, end) of n units owned by part `part` of `parts` (sizes differ by at

@@ -2196,10 +2196,8 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     P.confidence = confidence;
     P.fixed_iters = fixed_iters;
     const int HR = 512;   // largest round
-    // study switch (read at every call): the minimal solver without refinement, second chart or
-    // duplicate drop, to measure what those add
-    const char* lit_env = getenv("VO_FIVE_POINT_LITERAL");
-    const int literal = lit_env && atoi(lit_env) != 0;
+    // the minimal solver without refinement, second chart or duplicate drop, as OpenCV runs it
+    const int literal = c->opt[VO_OPT_FIVE_POINT_LITERAL];
     int rc;
     int nm = std::max(n_max, 1);
     if ((rc = ensure(c, c->r_state, (size_t)batch * sizeof(RState)))) return rc;
@@ -2270,8 +2268,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         // a stream of its own beside the scoring of the first pass's models, and scoring what it
         // adds afterwards, measured no faster: the chain is short against the scoring kernel and
         // the two event hand-offs per round cost what the overlap gains.)
-        static const bool no_retry = getenv("VO_NO_RETRY") != nullptr;   // measurement aid
-        if (!no_retry && !literal) {
+        if (c->opt[VO_OPT_SECOND_CHART] && !literal) {
             hipLaunchKernelGGL(retry_front_kernel, dim3(256), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
                                (const int32_t*)retry_list, recs);
             hipLaunchKernelGGL(retry_back_kernel, dim3(64), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
