@@ -153,7 +153,11 @@ enum {
      * blocks x chunks, merged by a second kernel): 0 (default) by size, 1 never,
      * else 2..64.  Environment: VO_KNN_SPLIT. */
     VO_OPT_KNN_TRAIN_SPLIT = 6,
-    VO_OPT_COUNT = 7
+    /* Root kernel of the five-point solver: 0 (default) one wavefront per eight
+     * hypotheses, 1 one 512-lane workgroup per 64 (tuning aid; the roots do not
+     * depend on it).  Environment: VO_SOLVE_VARIANT. */
+    VO_OPT_SOLVE_VARIANT = 7,
+    VO_OPT_COUNT = 8
 };
 int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
 int vo_ctx_get_option(const vo_ctx* ctx, int option, int* value);

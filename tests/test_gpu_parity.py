@@ -530,7 +530,54 @@ def test_find_essential_shared_hypotheses(ctx, oracle, seed):
     assert np.max(np.abs(gE - s * oE)) < 1e-8
 
 
-@pytest.mark.parametrize("fixed", [64, 700])
+def test_fixed_count_in_several_large_rounds(ctx):
+    """A fixed hypothesis count is drawn up front and solved in one round; a batch whose pairs x count
+    exceeds 2^18 hypotheses takes several such rounds.  Three pairs with 100 000 hypotheses each (two
+    rounds) must give the records each pair gets alone (one round)."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for k in range(3):
+        frames.extend(synth.frame_pair(700 + k))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+
+    def run(first, n):
+        res = torch.zeros(n * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.pipeline_pairs_dev(imgs[2 * first:].data_ptr(), n, 480, 640, 640, 480 * 640, 1000, 0.75, TUM_K, 1.0, 0.999,
+                               100000, res.data_ptr())
+        ctx.sync()
+        return res.cpu().numpy().tobytes()
+
+    together = run(0, 3)
+    alone = b"".join(run(k, 1) for k in range(3))
+    rec = np.frombuffer(together, capi.PAIR_DTYPE)
+    assert np.all(rec["ransac_iters"] == 100000) and np.all(rec["valid"] == 1)
+    assert together == alone
+
+
+def test_root_kernel_variants_agree(ctx, options):
+    """The root stage of the five-point solver exists as a one-wavefront kernel (the rounds' default)
+    and as a 512-lane workgroup (second-chart pass, VO_OPT_SOLVE_VARIANT = 1): same pieces, same
+    bookkeeping, so the RANSAC outcome must not depend on which one a round uses."""
+    p1, p2 = None, None
+    out = []
+    for variant in (0, 1):
+        options("solve_variant", variant)
+        res = []
+        for seed in (21, 24):
+            a, b = synth.frame_pair(seed, sparse=True, moving_fraction=0.6, n_layers=24)
+            k1, k2, qi, ti, _ = ctx.match_images(a, b, 2000)
+            p1 = np.stack([k1["x"][qi], k1["y"][qi]], 1)
+            p2 = np.stack([k2["x"][ti], k2["y"][ti]], 1)
+            res.append(ctx.find_essential(p1, p2, TUM_K))
+        out.append(res)
+    for a, b in zip(*out):
+        assert a[0] == b[0] and a[3] == b[3] and a[3] > 100          # inliers, iterations (several rounds)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+        assert np.max(np.abs(a[1] - b[1])) < 1e-12
+
+
+@pytest.mark.parametrize("fixed", [64, 700, 1500])
 def test_find_essential_fixed_hypothesis_count(ctx, oracle, fixed):
     p1, p2 = _matched_points(oracle, 24, 1000)
     rng = np.random.default_rng(3)
@@ -583,20 +630,29 @@ def _same_model_sets(ctx, oracle, p1, p2, K, samples):
     return -1
 
 
+# The one scene of test_random_two_view_scenes on which GPU and oracle end differently, with what explains
+# it (tools/enumerate_exceptions.py): case id -> ((GPU inliers, iterations), (oracle inliers, iterations),
+# index of the first minimal sample whose model sets differ, that sample).
+TWO_VIEW_EXCEPTIONS = {
+    56: ((144, 600), (162, 600), 146, (296, 184, 63, 144, 237)),   # kind 0, 300 matches, 600 fixed hypotheses
+}
+
+
 def test_random_two_view_scenes(ctx, oracle):
     """Geometric scenes instead of matched ORB points: planar and small-rotation scenes, noise-free
     data on which every model of a hypothesis has all points as inliers (the winner among equals is
     the first in a chart-independent order), 5 to 3000 matches, up to 90 % outliers, fixed and
     adaptive hypothesis counts.  Sample sets, iteration count, inlier mask and model must be
-    identical - unless the two five-point stages report different model sets for one of the minimal
-    samples walked: both approximate the complete solution set (the oracle by the union over four
-    charts of the null space, the GPU by one chart and a second for odd model counts) and differ on
-    about one minimal sample in a thousand (tools/dbg_model_sets.py); such a scene is only counted.
+    identical.  Both five-point stages approximate the complete solution set (the oracle by the union
+    over four charts of the null space, the GPU by one chart and a second for odd model counts) and
+    differ on about one minimal sample in a thousand (tools/dbg_model_sets.py); the scenes where such
+    a sample changes the outcome are listed one by one in TWO_VIEW_EXCEPTIONS with the sample that
+    explains them, and anything else fails.
     Inputs that are not well-posed (pure rotation, a baseline of a five-hundredth of the depth, sets
     full of repeated points) leave the minimal problem rank-deficient or nearly so and are skipped:
     which of a cluster of solutions a solver reports there is a matter of its root finder
     (tools/fuzz_ransac.py lists them)."""
-    done = incomplete = 0
+    done, seen = 0, {}
     for case in range(110):
         rng = np.random.default_rng(1000003 * 7 + case)
         p1, p2, K, thr, fixed, (kind, noise, baseline) = synth.two_view_scene(rng)
@@ -613,25 +669,27 @@ def test_random_two_view_scenes(ctx, oracle):
             s = 1.0 if np.sum(gE * oE) > 0 else -1.0
             same = np.max(np.abs(gE - s * oE)) < 1e-8
         if not same:
-            assert len(p1) > 5 and _same_model_sets(ctx, oracle, p1, p2, K, osamp[:k]) >= 0, tag
-            incomplete += 1
+            h = _same_model_sets(ctx, oracle, p1, p2, K, osamp[:k])
+            seen[case] = ((gg, git), (og, oit), h, tuple(int(v) for v in osamp[h]) if h >= 0 else None)
             continue
         om_ = oracle.estimate_motion(p1, p2, K, threshold=thr, fixed_iters=fixed)
         gm_ = ctx.estimate_motion(p1, p2, K, threshold=thr, fixed_iters=fixed)
         assert bool(om_["valid"]) == bool(gm_["valid"]) and om_["inliers"] == gm_["inliers"], tag
         if om_["valid"]:
             assert np.max(np.abs(om_["R"] - gm_["R"])) < 1.7e-4 and np.max(np.abs(om_["t"] - gm_["t"])) < 1e-4, tag
-    assert done >= 40 and incomplete <= 2, (done, incomplete)
+    assert done >= 40
+    assert seen == TWO_VIEW_EXCEPTIONS
 
 
-@pytest.mark.parametrize("name", ["forward", "rotation"])
+@pytest.mark.parametrize("name", ["forward", "rotation", "forward_zyx", "rotation_zyx"])
 def test_reference_motion_scenes(ctx, oracle, name):
     # ref:tests/test_motion_estimator.cpp:61-102 plus agreement with the oracle and the ground truth
+    # (the _zyx files hold the points a g++ build of that test draws, the others a clang build's)
     z = np.load(os.path.join(GOLD, f"motion_scene_{name}.npz"))
     g = ctx.estimate_motion(z["p1"], z["p2"], KITTI_K)
     o = oracle.estimate_motion(z["p1"], z["p2"], KITTI_K)
     assert g["valid"] and g["inliers"] > 50
-    if name == "forward":
+    if name.startswith("forward"):
         assert g["t"][2] > 0.9
     assert g["inliers"] == o["inliers"]
     assert _rot_err_deg(g["R"], o["R"]) < 0.01                 # degrees
@@ -664,7 +722,7 @@ def test_degenerate_pure_translation(ctx, oracle):
     g = ctx.estimate_motion(p1, p2, TUM_K)
     o = oracle.estimate_motion(p1, p2, TUM_K)
     assert g["valid"] and o["valid"]
-    assert abs(g["inliers"] - o["inliers"]) <= 2
+    assert g["inliers"] == o["inliers"] and np.array_equal(g["mask"], o["mask"])
     assert _rot_err_deg(g["R"], o["R"]) < 0.01 and np.linalg.norm(g["t"] - o["t"]) < 1e-4
     assert _rot_err_deg(g["R"], np.eye(3)) < 0.05 and abs(abs(g["t"][0]) - 1) < 1e-3
 
@@ -687,8 +745,7 @@ def test_five_point_models_match_oracle(ctx, oracle):
         if len(ref) == len(got[i]) and all(
                 min(min(np.abs(E - F).max(), np.abs(E + F).max()) for F in ref) < 1e-8 for E in got[i]):
             same += 1
-    # independent root finders may disagree on which ill-conditioned roots exist in ~1% of sets
-    assert same >= 0.95 * n_sets
+    assert same == n_sets   # (two independent root finders; the refinement and the second chart make the sets complete)
 
 
 def test_five_point_with_a_repeated_point(ctx, oracle):
@@ -716,7 +773,9 @@ def test_five_point_with_a_repeated_point(ctx, oracle):
         if len(ref) == len(got[i]) and all(
                 min(min(np.abs(E - F).max(), np.abs(E + F).max()) for F in ref) < 1e-8 for E in got[i]):
             same += 1
-    print("repeated-point sets: GPU models", n_models, "sets equal to the oracle's", same, "of", n_sets)
+    # (nothing is asserted about which members of the family come out: the oracle's four charts and
+    # the GPU's two pick different ones - on no set of this test do the two lists coincide)
+    assert n_models > 0
 
 
 def test_motion_validity_rules(ctx):

@@ -30,9 +30,9 @@ for case in range(110):
         same = np.max(np.abs(gE - s * oE)) < 1e-8
     if not same:
         k = min(git, oit)
-        h = T._same_model_sets(ctx, O, p1, p2, K, osamp[:k])
+        h = T._same_model_sets(ctx, O, p1, p2, K, osamp[:k]) if k > 0 else -1
         diff.append({"case": case, "kind": int(kind), "n": len(p1), "fixed": int(fixed), "gpu": [int(gg), int(git)],
-                     "oracle": [int(og), int(oit)], "first_differing_sample": int(h),
+                     "oracle": [int(og), int(oit)], "thr": float(thr), "first_differing_sample": int(h),
                      "sample": osamp[h].tolist() if h >= 0 else None})
 out["random_two_view_scenes"] = diff
 print(diff, flush=True)

@@ -128,6 +128,7 @@ static bool option_admits(int option, int v) {
         case VO_OPT_KNN_QUERIES_PER_LANE: return v == 0 || v == 1 || v == 2 || v == 4;
         case VO_OPT_SECOND_CHART: return v == 0 || v == 1;
         case VO_OPT_KNN_TRAIN_SPLIT: return v >= 0 && v <= 64;
+        case VO_OPT_SOLVE_VARIANT: return v == 0 || v == 1;
         default: return false;
     }
 }
@@ -137,7 +138,7 @@ static void option_defaults(vo_ctx* c) {
         {VO_OPT_FIVE_POINT_LITERAL, "VO_FIVE_POINT_LITERAL", 0}, {VO_OPT_FAST_RAISE, "VO_FAST_RAISE", -1},
         {VO_OPT_KNN_MODE, "VO_KNN_MODE", -1},                     {VO_OPT_KNN_WAVES, "VO_KNN_NW", 0},
         {VO_OPT_KNN_QUERIES_PER_LANE, "VO_KNN_QPL", 0},           {VO_OPT_SECOND_CHART, "VO_SECOND_CHART", 1},
-        {VO_OPT_KNN_TRAIN_SPLIT, "VO_KNN_SPLIT", 0}};
+        {VO_OPT_KNN_TRAIN_SPLIT, "VO_KNN_SPLIT", 0},              {VO_OPT_SOLVE_VARIANT, "VO_SOLVE_VARIANT", 0}};
     for (const auto& t : table) {
         int v = t.dflt;
         if (const char* e = getenv(t.env)) {

@@ -125,6 +125,12 @@ __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------ five-point solver
+// From here to the scoring kernel multiplications and additions may fuse: every model the solver
+// hands on is the fixed point of the refinement on the constraints, which does not depend on how
+// the elimination and the root search before it were rounded, and the fused forms halve the
+// dependent chains these kernels consist of.  (Scoring, bookkeeping and pose recovery keep the
+// translation unit's default - no contraction -, where an operation order is part of the result.)
+#pragma clang fp contract(fast)
 constexpr int ST = 16;   // lanes per solve workgroup (one hypothesis each): 25 KB of LDS, so a workgroup fits
                          // beside the resident tiles of a concurrently running image kernel
 
@@ -797,18 +803,21 @@ constexpr int BACK_THREADS = 512;   // eight wavefronts: one sweep covers a leve
 constexpr int HYP_REC = 88;   // doubles: flag, cf[11], bm[3][13], EE[4][9], one pad
 constexpr int PIECES = 11;    // at most ten roots of the next derivative -> eleven pieces
 
-struct RootsShared {             // the nine derivative levels
-    double cf[HB][11];
-    double list[HB][2][12];      // the two alternating root lists
-    double px[HB][PIECES];       // bracketed root of a piece
-    double bound[HB];            // root bound R of the current level
-    uint8_t ptype[HB][12];       // per piece: 1 left end is an exact zero, 2 bracketed root,
+template <int NHR>               // hypotheses per workgroup (at most 64: one wavefront numbers the pieces)
+struct RootsSharedT {            // the nine derivative levels
+    static constexpr int kHyp = NHR;
+    double cf[NHR][11];
+    double list[NHR][2][12];     // the two alternating root lists
+    double px[NHR][PIECES];      // bracketed root of a piece
+    double bound[NHR];           // root bound R of the current level
+    uint8_t ptype[NHR][12];      // per piece: 1 left end is an exact zero, 2 bracketed root,
                                  // 4 right end is a touching extremum
-    uint16_t map[HB * PIECES];   // work item -> hypothesis | index << 8
-    int16_t np[HB];              // roots in the current list
-    uint8_t deg[HB];             // degree of the hypothesis' polynomial (0: nothing to solve)
+    uint16_t map[NHR * PIECES];  // work item -> hypothesis | index << 8
+    int16_t np[NHR];             // roots in the current list
+    uint8_t deg[NHR];            // degree of the hypothesis' polynomial (0: nothing to solve)
     int total;
 };
+using RootsShared = RootsSharedT<HB>;
 constexpr int HBM = 96;           // hypotheses per workgroup of the model stage on its own: 4.4 candidates each on
                                   // average, 420 of the 512 lanes busy (64 hypotheses leave 45 % of them idle, and at
                                   // 244 registers per lane nothing else is resident to use the slots)
@@ -871,172 +880,184 @@ __device__ __forceinline__ void number_items_wide(SH& sh) {
     __syncthreads();
 }
 
+// One piece g of hypothesis h on the derivative level of degree DEG: list `si` holds the roots of the
+// next derivative; records what the piece contributes (ptype) and its bracketed root (px).
+template <int DEG, class RS>
+__device__ __forceinline__ void root_piece(RS& sh, int si, int h, int g) {
+    constexpr int J = 10 - DEG;
+    const int np = sh.np[h];
+    const int e = (int)sh.deg[h] - J;   // 1 .. DEG
+    double d[DEG + 1], dd[DEG];
+#pragma unroll
+    for (int i = 0; i <= DEG; ++i) d[i] = sh.cf[h][i + J] * falling(i + J, J);
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
+    // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
+    double R = 0, lead = d[DEG];
+#pragma unroll
+    for (int i = 0; i < DEG; ++i) {
+        if (i < e) R = fmax(R, fabs(d[i]));
+        if (i == e) lead = d[i];
+    }
+    R = R / fabs(lead) * (1.0 + 1e-12) + 1.0;
+    if (g == 0) sh.bound[h] = R;
+    const double* sP = sh.list[h][si];
+    // Inner pieces lie between two roots of the derivative.  The two outer pieces are
+    // unbounded: whether they hold a root follows from the sign at the inner end and the
+    // sign at infinity, and the far end of the bracket is found by stepping outwards with
+    // a step that grows fourfold (Newton from the middle of [end, +-R] would crawl, it
+    // gains only a factor (DEG-1)/DEG per step while far from the roots).
+    const bool left_open = g == 0, right_open = g == np;
+    double a, b, fa, fb;
+    if (!left_open) {
+        a = fmin(fmax(sP[g - 1], -R), R);
+        fa = horner<DEG>(d, a);
+    }
+    if (!right_open) {
+        b = fmin(fmax(sP[g], -R), R);
+        fb = horner<DEG>(d, b);
+    }
+    const double bT = right_open ? 0.0 : b, fbT = right_open ? 0.0 : fb;   // inner right end, for the extremum test
+    const bool lead_neg = lead < 0;
+    bool at_pivot = false;   // monotone polynomial with a zero exactly at the pivot
+    if (left_open || right_open) {
+        double p, fp, dir;
+        if (left_open && right_open) {   // no extremum at all: monotone, pivot at 0
+            p = 0.0;
+            fp = d[0];
+            dir = ((fp < 0) != lead_neg) ? 1.0 : -1.0;   // towards the sign opposite to fp
+            at_pivot = fp == 0.0;
+        } else if (right_open) {
+            p = a; fp = fa; dir = 1.0;
+        } else {
+            p = b; fp = fb; dir = -1.0;
+        }
+        // sign of the polynomial at dir * infinity
+        const bool inf_neg = dir > 0 ? lead_neg : (lead_neg != ((e & 1) != 0));
+        double q = p, fq = fp;
+        if (fp != 0.0 && ((fp < 0) != inf_neg)) {
+            double step = 1e-3 * fmax(1.0, fabs(p));
+            for (int it = 0; it < 64; ++it) {
+                double x = p + dir * step;
+                if (fabs(x) > R) x = dir * R;
+                double fx = horner<DEG>(d, x);
+                if (fx == 0.0 || ((fx < 0) != (fp < 0)) || fabs(x) >= R) {
+                    p = q; fp = fq;   // last point on the near side
+                    q = x; fq = fx;
+                    break;
+                }
+                q = x; fq = fx;
+                step *= 4.0;
+            }
+        }
+        // [p, q] (in the direction dir) is the bracket, or p == q if there is no root
+        if (dir > 0) { a = p; fa = fp; b = q; fb = fq; }
+        else { a = q; fa = fq; b = p; fb = fp; }
+    }
+    const bool inc = b > a;
+    const bool cA = inc && fa == 0.0 && !left_open;
+    const bool cX = at_pivot || (inc && ((fa != 0.0 && ((fa < 0) != (fb < 0)) && fb != 0.0) ||
+                                         (left_open && fa == 0.0) || (right_open && fb == 0.0)));
+    if (cX) {
+        double x;
+        if (at_pivot) x = 0.0;
+        else if (left_open && fa == 0.0) x = a;     // the probe hit the root exactly
+        else if (right_open && fb == 0.0) x = b;
+        else {
+            double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
+            x = 0.5 * (a + b);
+            double dxold = fabs(b - a), dx = dxold;
+            double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
+            // The roots of the derivatives only delimit pieces and the final roots are
+            // refined afterwards, so 1e-10 (1e-12 on the last level) relative is enough;
+            // pieces that converge linearly (a root next to an extremum) stop at 40 steps.
+            constexpr double tol = DEG < 10 ? 1e-10 : 1e-12;
+            for (int it = 0; it < 40; ++it) {
+                if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+                    dxold = dx;
+                    dx = 0.5 * (xh - xl);
+                    x = xl + dx;
+                } else {
+                    dxold = dx;
+                    dx = f / df;
+                    x -= dx;
+                }
+                if (fabs(dx) <= tol * fmax(1.0, fabs(x))) break;
+                f = horner<DEG>(d, x);
+                df = horner<DEG - 1>(dd, x);
+                if (f == 0.0) break;
+                if (f < 0.0) xl = x; else xh = x;
+            }
+        }
+        sh.px[h][g] = x;
+    }
+    bool cT = false;
+    if (DEG == 10 && !right_open && fbT != 0.0) {
+        // a local extremum within 1e-4 of zero, relative to the polynomial's magnitude there: a
+        // double root or a pair of close roots lost to the elimination's rounding - a candidate
+        double ab = fabs(bT), mag = fabs(d[DEG]);
+#pragma unroll
+        for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
+        cT = fabs(fbT) <= 1e-4 * mag;
+    }
+    sh.ptype[h][g] = (uint8_t)((cA ? 1 : 0) | (cX ? 2 : 0) | (cT ? 4 : 0));
+}
+
+// The ordered bookkeeping of the one-lane routine for hypothesis h: the pieces' contributions in
+// ascending order become list 1 - si.
+template <int DEG, class RS>
+__device__ __forceinline__ void root_collect(RS& sh, int si, int h) {
+const int np = sh.np[h];
+    const double R = sh.bound[h];
+    const double* sP = sh.list[h][si];
+    double* sC = sh.list[h][1 - si];
+    int nc = 0;
+    double last = 0;
+    for (int g = 0; g <= np; ++g) {
+        const int ty = sh.ptype[h][g];
+        if (ty == 0) continue;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (!((ty >> t) & 1)) continue;
+            double v;
+            if (t == 0) v = fmin(fmax(sP[g - 1], -R), R);    // never set for the first piece
+            else if (t == 1) v = sh.px[h][g];
+            else v = fmin(fmax(sP[g], -R), R);               // never set for the last piece
+            const bool near = nc > 0 && fabs(v - last) <= 1e-7 * fmax(1.0, fabs(v));
+            bool push;
+            if (t == 0) push = nc == 0 || last != v;
+            else if (t == 1) push = !(DEG == 10 && near);
+            // a touching extremum is the double root itself only when neither neighbouring
+            // piece holds a bracketed root (next to one, the bracketed roots are the two solutions)
+            else push = !near && !(ty & 2) && !(sh.ptype[h][g + 1] & 2);
+            if (push && nc < 10) {
+                sC[nc] = v;
+                last = v;
+                ++nc;
+            }
+        }
+    }
+    sh.np[h] = (int16_t)nc;
+}
+
 // One derivative level (degree DEG) for the whole workgroup: list `si` holds the roots of the
 // next derivative, the roots of this one go to list 1 - si (ascending).
-template <int DEG>
-__device__ __forceinline__ void roots_level_block(RootsShared& sh, int si) {
+template <int DEG, int T, class RS>   // T: threads of the workgroup
+__device__ __forceinline__ void roots_level_block(RS& sh, int si) {
     const int tid = threadIdx.x;
     constexpr int J = 10 - DEG;
+    constexpr int NHR = RS::kHyp;
     // A polynomial of degree n < 10 (its upper coefficients are stored as zeros) joins at the
     // level where its J-th derivative is linear - one unbounded piece, no list yet - and from
     // there on is a polynomial of degree e = n - J inside the arrays of degree DEG.
-    if (tid < 64) number_items(sh, tid, (int)sh.deg[tid] - J >= 1 ? sh.np[tid] + 1 : 0);
+    if (tid < 64) number_items(sh, tid, tid < NHR && (int)sh.deg[tid] - J >= 1 ? sh.np[tid] + 1 : 0);
     __syncthreads();
     const int total = sh.total;
-    for (int item = tid; item < total; item += BACK_THREADS) {
-        const int h = sh.map[item] & 0xFF, g = sh.map[item] >> 8;
-        const int np = sh.np[h];
-        const int e = (int)sh.deg[h] - J;   // 1 .. DEG
-        double d[DEG + 1], dd[DEG];
-#pragma unroll
-        for (int i = 0; i <= DEG; ++i) d[i] = sh.cf[h][i + J] * falling(i + J, J);
-#pragma unroll
-        for (int i = 0; i < DEG; ++i) dd[i] = d[i + 1] * (double)(i + 1);
-        // Cauchy bound on the roots (one division; any bound serves, the roots do not depend on it)
-        double R = 0, lead = d[DEG];
-#pragma unroll
-        for (int i = 0; i < DEG; ++i) {
-            if (i < e) R = fmax(R, fabs(d[i]));
-            if (i == e) lead = d[i];
-        }
-        R = R / fabs(lead) * (1.0 + 1e-12) + 1.0;
-        if (g == 0) sh.bound[h] = R;
-        const double* sP = sh.list[h][si];
-        // Inner pieces lie between two roots of the derivative.  The two outer pieces are
-        // unbounded: whether they hold a root follows from the sign at the inner end and the
-        // sign at infinity, and the far end of the bracket is found by stepping outwards with
-        // a step that grows fourfold (Newton from the middle of [end, +-R] would crawl, it
-        // gains only a factor (DEG-1)/DEG per step while far from the roots).
-        const bool left_open = g == 0, right_open = g == np;
-        double a, b, fa, fb;
-        if (!left_open) {
-            a = fmin(fmax(sP[g - 1], -R), R);
-            fa = horner<DEG>(d, a);
-        }
-        if (!right_open) {
-            b = fmin(fmax(sP[g], -R), R);
-            fb = horner<DEG>(d, b);
-        }
-        const double bT = right_open ? 0.0 : b, fbT = right_open ? 0.0 : fb;   // inner right end, for the extremum test
-        const bool lead_neg = lead < 0;
-        bool at_pivot = false;   // monotone polynomial with a zero exactly at the pivot
-        if (left_open || right_open) {
-            double p, fp, dir;
-            if (left_open && right_open) {   // no extremum at all: monotone, pivot at 0
-                p = 0.0;
-                fp = d[0];
-                dir = ((fp < 0) != lead_neg) ? 1.0 : -1.0;   // towards the sign opposite to fp
-                at_pivot = fp == 0.0;
-            } else if (right_open) {
-                p = a; fp = fa; dir = 1.0;
-            } else {
-                p = b; fp = fb; dir = -1.0;
-            }
-            // sign of the polynomial at dir * infinity
-            const bool inf_neg = dir > 0 ? lead_neg : (lead_neg != ((e & 1) != 0));
-            double q = p, fq = fp;
-            if (fp != 0.0 && ((fp < 0) != inf_neg)) {
-                double step = 1e-3 * fmax(1.0, fabs(p));
-                for (int it = 0; it < 64; ++it) {
-                    double x = p + dir * step;
-                    if (fabs(x) > R) x = dir * R;
-                    double fx = horner<DEG>(d, x);
-                    if (fx == 0.0 || ((fx < 0) != (fp < 0)) || fabs(x) >= R) {
-                        p = q; fp = fq;   // last point on the near side
-                        q = x; fq = fx;
-                        break;
-                    }
-                    q = x; fq = fx;
-                    step *= 4.0;
-                }
-            }
-            // [p, q] (in the direction dir) is the bracket, or p == q if there is no root
-            if (dir > 0) { a = p; fa = fp; b = q; fb = fq; }
-            else { a = q; fa = fq; b = p; fb = fp; }
-        }
-        const bool inc = b > a;
-        const bool cA = inc && fa == 0.0 && !left_open;
-        const bool cX = at_pivot || (inc && ((fa != 0.0 && ((fa < 0) != (fb < 0)) && fb != 0.0) ||
-                                             (left_open && fa == 0.0) || (right_open && fb == 0.0)));
-        if (cX) {
-            double x;
-            if (at_pivot) x = 0.0;
-            else if (left_open && fa == 0.0) x = a;     // the probe hit the root exactly
-            else if (right_open && fb == 0.0) x = b;
-            else {
-                double xl = fa < 0 ? a : b, xh = fa < 0 ? b : a;
-                x = 0.5 * (a + b);
-                double dxold = fabs(b - a), dx = dxold;
-                double f = horner<DEG>(d, x), df = horner<DEG - 1>(dd, x);
-                // The roots of the derivatives only delimit pieces and the final roots are
-                // refined afterwards, so 1e-10 (1e-12 on the last level) relative is enough;
-                // pieces that converge linearly (a root next to an extremum) stop at 40 steps.
-                constexpr double tol = DEG < 10 ? 1e-10 : 1e-12;
-                for (int it = 0; it < 40; ++it) {
-                    if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
-                        dxold = dx;
-                        dx = 0.5 * (xh - xl);
-                        x = xl + dx;
-                    } else {
-                        dxold = dx;
-                        dx = f / df;
-                        x -= dx;
-                    }
-                    if (fabs(dx) <= tol * fmax(1.0, fabs(x))) break;
-                    f = horner<DEG>(d, x);
-                    df = horner<DEG - 1>(dd, x);
-                    if (f == 0.0) break;
-                    if (f < 0.0) xl = x; else xh = x;
-                }
-            }
-            sh.px[h][g] = x;
-        }
-        bool cT = false;
-        if (DEG == 10 && !right_open && fbT != 0.0) {
-            // a local extremum within 1e-4 of zero, relative to the polynomial's magnitude there: a
-            // double root or a pair of close roots lost to the elimination's rounding - a candidate
-            double ab = fabs(bT), mag = fabs(d[DEG]);
-#pragma unroll
-            for (int i = DEG - 1; i >= 0; --i) mag = mag * ab + fabs(d[i]);
-            cT = fabs(fbT) <= 1e-4 * mag;
-        }
-        sh.ptype[h][g] = (uint8_t)((cA ? 1 : 0) | (cX ? 2 : 0) | (cT ? 4 : 0));
+    for (int item = tid; item < total; item += T) {
+        root_piece<DEG>(sh, si, sh.map[item] & 0xFF, sh.map[item] >> 8);
     }
     __syncthreads();
-    // the ordered bookkeeping of the one-lane routine, one lane per hypothesis
-    if (tid < HB && (int)sh.deg[tid] - J >= 1) {
-        const int h = tid, np = sh.np[h];
-        const double R = sh.bound[h];
-        const double* sP = sh.list[h][si];
-        double* sC = sh.list[h][1 - si];
-        int nc = 0;
-        double last = 0;
-        for (int g = 0; g <= np; ++g) {
-            const int ty = sh.ptype[h][g];
-            if (ty == 0) continue;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (!((ty >> t) & 1)) continue;
-                double v;
-                if (t == 0) v = fmin(fmax(sP[g - 1], -R), R);    // never set for the first piece
-                else if (t == 1) v = sh.px[h][g];
-                else v = fmin(fmax(sP[g], -R), R);               // never set for the last piece
-                const bool near = nc > 0 && fabs(v - last) <= 1e-7 * fmax(1.0, fabs(v));
-                bool push;
-                if (t == 0) push = nc == 0 || last != v;
-                else if (t == 1) push = !(DEG == 10 && near);
-                // a touching extremum is the double root itself only when neither neighbouring
-                // piece holds a bracketed root (next to one, the bracketed roots are the two solutions)
-                else push = !near && !(ty & 2) && !(sh.ptype[h][g + 1] & 2);
-                if (push && nc < 10) {
-                    sC[nc] = v;
-                    last = v;
-                    ++nc;
-                }
-            }
-        }
-        sh.np[h] = (int16_t)nc;
-    }
+    if (tid < NHR && (int)sh.deg[tid] - J >= 1) root_collect<DEG>(sh, si, tid);
     __syncthreads();
 }
 
@@ -1072,10 +1093,11 @@ __device__ __forceinline__ void solve_front(bool active, const double* x1, const
 //
 // Stage 1: real roots of the hypotheses' degree-10 polynomials; on return sh.list[h][1][0..np[h])
 // holds them in ascending order.
-__device__ __forceinline__ void roots_block(RootsShared& sh, int count, const double* __restrict__ rec0) {
-    const int tid = threadIdx.x;
-    if (tid < HB) {
-        const int h = tid;
+// Takes hypothesis h's polynomial out of its record: coefficients, degree, the root of the ninth
+// derivative as the first list.
+template <class RS>
+__device__ __forceinline__ void roots_init(RS& sh, int h, int count, const double* __restrict__ rec0) {
+    {
         const double* rec = rec0 + (size_t)h * HYP_REC;
         int np = 0, n = 0;
         if (h < count && rec[0] != 0.0) {
@@ -1106,16 +1128,69 @@ __device__ __forceinline__ void roots_block(RootsShared& sh, int count, const do
         sh.np[h] = (int16_t)np;
         sh.deg[h] = (uint8_t)n;
     }
+}
+
+template <int T, class RS>
+__device__ __forceinline__ void roots_block(RS& sh, int count, const double* __restrict__ rec0) {
+    if ((int)threadIdx.x < RS::kHyp) roots_init(sh, threadIdx.x, count, rec0);
     __syncthreads();
-    roots_level_block<2>(sh, 0);
-    roots_level_block<3>(sh, 1);
-    roots_level_block<4>(sh, 0);
-    roots_level_block<5>(sh, 1);
-    roots_level_block<6>(sh, 0);
-    roots_level_block<7>(sh, 1);
-    roots_level_block<8>(sh, 0);
-    roots_level_block<9>(sh, 1);
-    roots_level_block<10>(sh, 0);   // the roots end up in list 1, their number in np
+    roots_level_block<2, T>(sh, 0);
+    roots_level_block<3, T>(sh, 1);
+    roots_level_block<4, T>(sh, 0);
+    roots_level_block<5, T>(sh, 1);
+    roots_level_block<6, T>(sh, 0);
+    roots_level_block<7, T>(sh, 1);
+    roots_level_block<8, T>(sh, 0);
+    roots_level_block<9, T>(sh, 1);
+    roots_level_block<10, T>(sh, 0);   // the roots end up in list 1, their number in np
+}
+
+// The same stage one wavefront at a time: a workgroup is a single wavefront that takes RW_H
+// hypotheses with RW_L lanes each; lane j of a hypothesis runs its pieces j, j + RW_L, ... (a
+// polynomial of degree ten rarely offers more than eight pieces on a level), the first lane of a
+// hypothesis does the ordered bookkeeping.  The barriers between the passes then are a
+// wavefront's own (the hardware has nothing to wait for), wavefronts progress independently and
+// six of them per SIMD hide one another's dependent chains - where 512 lanes behind workgroup
+// barriers waited nine times for the slowest of some 220 pieces and for 64 lanes' bookkeeping.
+constexpr int RW_H = 8, RW_L = 8;
+template <int DEG, class RS>
+__device__ __forceinline__ void roots_level_wave(RS& sh, int si) {
+    constexpr int J = 10 - DEG;
+    const int h = threadIdx.x / RW_L, sub = threadIdx.x % RW_L;
+    const bool on = (int)sh.deg[h] - J >= 1;
+    const int items = on ? sh.np[h] + 1 : 0;
+    for (int g = sub; g < items; g += RW_L) root_piece<DEG>(sh, si, h, g);
+    __syncthreads();
+    if (sub == 0 && on) root_collect<DEG>(sh, si, h);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(RW_H * RW_L, 6) void solve_roots_wave_kernel(const RState* __restrict__ st, int hr,
+                                                                         const double* __restrict__ recs,
+                                                                         double* __restrict__ roots,
+                                                                         int32_t* __restrict__ nroots) {
+    static_assert(RW_H * RW_L == 64, "one wavefront per workgroup");
+    __shared__ RootsSharedT<RW_H> sh;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (st[b].done) return;
+    const int h0 = blockIdx.x * RW_H, count = min(RW_H, hr - h0);
+    const size_t slot = (size_t)b * hr + h0;
+    if (tid < RW_H) roots_init(sh, tid, count, recs + slot * HYP_REC);
+    __syncthreads();
+    roots_level_wave<2>(sh, 0);
+    roots_level_wave<3>(sh, 1);
+    roots_level_wave<4>(sh, 0);
+    roots_level_wave<5>(sh, 1);
+    roots_level_wave<6>(sh, 0);
+    roots_level_wave<7>(sh, 1);
+    roots_level_wave<8>(sh, 0);
+    roots_level_wave<9>(sh, 1);
+    roots_level_wave<10>(sh, 0);
+    for (int i = tid; i < count * kMaxModels; i += RW_H * RW_L) {
+        const int h = i / kMaxModels, k = i - h * kMaxModels;
+        if (k < sh.np[h]) roots[(slot + h) * kMaxModels + k] = sh.list[h][1][k];
+    }
+    if (tid < count) nroots[slot + tid] = sh.np[tid];
 }
 
 // Stage 2: the roots become models.  roots[h * roots_stride + r], r < sh.np[h] (set by the caller,
@@ -1123,7 +1198,7 @@ __device__ __forceinline__ void roots_block(RootsShared& sh, int count, const do
 // their number to nm0[h].
 // literal != 0 (study switch, VO_FIVE_POINT_LITERAL): the models are taken from the roots as they
 // stand - no refinement, no residual gate, no duplicate drop - as OpenCV's solver leaves them.
-template <int NH>
+template <int NH, int T>   // T: threads of the workgroup (at least 128, see number_items_wide)
 __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, const double* __restrict__ rec0,
                                              const double* roots, int roots_stride, double* __restrict__ Es0,
                                              int32_t* __restrict__ nm0, int literal) {
@@ -1139,7 +1214,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
     constexpr int kFirstSteps = 4;
     if (tid == 0) sh.nstrag = 0;
     __syncthreads();
-    for (int item = tid; item < total; item += BACK_THREADS) {
+    for (int item = tid; item < total; item += T) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         const double* rec = rec0 + (size_t)h * HYP_REC;
         double z1 = roots[(size_t)h * roots_stride + r];
@@ -1172,7 +1247,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
     }
     __syncthreads();
     const int nstrag = sh.nstrag;
-    for (int i = tid; i < nstrag; i += BACK_THREADS) {
+    for (int i = tid; i < nstrag; i += T) {
         const int h = sh.strag[i] & 0xFF, r = sh.strag[i] >> 8;
         const double* rec = rec0 + (size_t)h * HYP_REC;
         double EE[4][9], Ev[9];
@@ -1192,7 +1267,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
     // Two starts that settled on the same solution count once: in root order, a candidate
     // falls if a kept earlier one is within 1e-7 (either sign).  The comparisons run one
     // lane per candidate, the ordered decision is bit arithmetic by one lane per hypothesis.
-    for (int item = tid; item < total; item += BACK_THREADS) {
+    for (int item = tid; item < total; item += T) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         uint32_t bits = 0;
         if (sh.acc[h][r] && !literal) {
@@ -1223,7 +1298,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
         nm0[h] = __popc(kept);
     }
     __syncthreads();
-    for (int item = tid; item < total; item += BACK_THREADS) {
+    for (int item = tid; item < total; item += T) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
         const uint32_t kept = sh.kept[h];
         if (!((kept >> r) & 1u)) continue;
@@ -1236,10 +1311,10 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
 // Both stages in one workgroup.
 __device__ __forceinline__ void solve_back_block(BackShared& sh, int count, const double* __restrict__ rec0,
                                                  double* __restrict__ Es0, int32_t* __restrict__ nm0, int literal = 0) {
-    roots_block(sh.r, count, rec0);
+    roots_block<BACK_THREADS>(sh.r, count, rec0);
     if (threadIdx.x < HB) sh.m.np[threadIdx.x] = sh.r.np[threadIdx.x];
     __syncthreads();
-    models_block(sh.m, count, rec0, &sh.r.list[0][1][0], 2 * 12, Es0, nm0, literal);
+    models_block<HB, BACK_THREADS>(sh.m, count, rec0, &sh.r.list[0][1][0], 2 * 12, Es0, nm0, literal);
 }
 
 __global__ __launch_bounds__(ST) void solve_front_kernel(const RState* __restrict__ st, const double* __restrict__ m,
@@ -1326,41 +1401,43 @@ __global__ __launch_bounds__(256) void merge_models_kernel(const int32_t* __rest
 }
 
 
-// (six wavefronts per SIMD = three workgroups per CU: the stage is a chain of short dependent
-// passes between barriers, so what hides its latency is other workgroups; 80 registers suffice)
-__global__ __launch_bounds__(BACK_THREADS, 6) void solve_roots_kernel(const RState* __restrict__ st, int hr,
+// (the root stage is a chain of short dependent passes between barriers, so what hides its latency
+// is other workgroups: 80 registers, six wavefronts per SIMD)
+template <int T, int NHR>
+__global__ __launch_bounds__(T, 6) void solve_roots_kernel(const RState* __restrict__ st, int hr,
                                                                    const double* __restrict__ recs,
                                                                    double* __restrict__ roots,
                                                                    int32_t* __restrict__ nroots) {
-    __shared__ RootsShared sh;
+    __shared__ RootsSharedT<NHR> sh;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
-    const int h0 = blockIdx.x * HB, count = min(HB, hr - h0);
+    const int h0 = blockIdx.x * NHR, count = min(NHR, hr - h0);
     const size_t slot = (size_t)b * hr + h0;
-    roots_block(sh, count, recs + slot * HYP_REC);
-    for (int i = tid; i < count * kMaxModels; i += BACK_THREADS) {
+    roots_block<T>(sh, count, recs + slot * HYP_REC);
+    for (int i = tid; i < count * kMaxModels; i += T) {
         const int h = i / kMaxModels, k = i - h * kMaxModels;
         if (k < sh.np[h]) roots[(slot + h) * kMaxModels + k] = sh.list[h][1][k];
     }
     if (tid < count) nroots[slot + tid] = sh.np[tid];
 }
 
-__global__ __launch_bounds__(BACK_THREADS) void solve_models_kernel(const RState* __restrict__ st, int hr,
-                                                                    const double* __restrict__ recs,
-                                                                    const double* __restrict__ roots,
-                                                                    const int32_t* __restrict__ nroots,
-                                                                    double* __restrict__ models,
-                                                                    int32_t* __restrict__ nmodels,
-                                                                    int32_t* __restrict__ retry_list, int literal) {
-    __shared__ ModelsShared<HBM> sh;
+template <int T, int NH>
+__global__ __launch_bounds__(T) void solve_models_kernel(const RState* __restrict__ st, int hr,
+                                                          const double* __restrict__ recs,
+                                                          const double* __restrict__ roots,
+                                                          const int32_t* __restrict__ nroots,
+                                                          double* __restrict__ models,
+                                                          int32_t* __restrict__ nmodels,
+                                                          int32_t* __restrict__ retry_list, int literal) {
+    __shared__ ModelsShared<NH> sh;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
-    const int h0 = blockIdx.x * HBM, count = min(HBM, hr - h0);
+    const int h0 = blockIdx.x * NH, count = min(NH, hr - h0);
     const size_t slot = (size_t)b * hr + h0;
-    if (tid < HBM) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
+    if (tid < NH) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
     __syncthreads();
-    models_block(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels, models + slot * kMaxModels * 9,
-                 nmodels + slot, literal);
+    models_block<NH, T>(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels,
+                        models + slot * kMaxModels * 9, nmodels + slot, literal);
     // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
     // the count it wrote itself)
     if (retry_list && tid < count && (nmodels[slot + tid] & 1))
@@ -1380,6 +1457,7 @@ __global__ __launch_bounds__(BACK_THREADS) void retry_back_kernel(const int32_t*
     }
 }
 
+#pragma clang fp contract(off)
 // The inlier test (float)(err) <= t2 without the division in the common case: the
 // double err = num / den rounds to a float <= t2 exactly when it lies below the midpoint
 // t2_mid between t2 and the next float, so num against t2_mid * den decides unless the two are
@@ -1593,10 +1671,16 @@ __device__ __forceinline__ int take_set(const uint16_t* v, int pos, int limit, i
     return pos;
 }
 
+// The round's arrays hold arr_stride hypotheses per pair; this call replays the hr <= 512 of them
+// from position arr_off on, which are the hypotheses h0 .. h0 + hr - 1 of the pair's sequence
+// (a large fixed-count round is replayed in several calls; hr = 0 only draws).  The next_round
+// sets drawn go to position out_off of the pair's sample block.  final_call != 0: no hypotheses follow.
 __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv, int batch, RParams P, int h0, int hr,
+                                                      int arr_stride, int arr_off,
                                                       const double* __restrict__ models, const int32_t* __restrict__ nmodels,
                                                       const int32_t* __restrict__ counts, int32_t* __restrict__ samples,
-                                                      int samples_stride, int next_round, int32_t* __restrict__ samples_log,
+                                                      int samples_stride, int next_round, int out_off, int final_call,
+                                                      int32_t* __restrict__ samples_log,
                                                       int log_cap, int32_t* __restrict__ retry_list) {
     __shared__ int32_t s_nm[UPD_MAX_HR];     // models of a hypothesis that take part
     __shared__ int32_t s_cnt[UPD_MAX_HR * kMaxModels];
@@ -1616,13 +1700,14 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
     const int n = stv[b].n, niters0 = stv[b].niters, exact5 = stv[b].exact5;
     const int live = min(hr, max(niters0 - h0, 0));   // hypotheses the serial loop can reach
     for (int h = tid; h < UPD_MAX_HR; h += UPD_T) {
-        int nm = h < live ? nmodels[(size_t)b * hr + h] : 0;
+        int nm = h < live ? nmodels[(size_t)b * arr_stride + arr_off + h] : 0;
         if (exact5 && nm != 1) nm = 0;
         s_nm[h] = nm;
     }
-    for (int i = tid; i < live * kMaxModels; i += UPD_T) s_cnt[i] = counts[(size_t)b * hr * kMaxModels + i];
+    for (int i = tid; i < live * kMaxModels; i += UPD_T)
+        s_cnt[i] = counts[((size_t)b * arr_stride + arr_off) * kMaxModels + i];
     if (samples_log) {
-        const int32_t* src = samples + (size_t)b * samples_stride;
+        const int32_t* src = samples + (size_t)b * samples_stride + (size_t)arr_off * 5;
         const int lim = min(live, log_cap - h0);
         for (int i = tid; i < lim * 5; i += UPD_T) samples_log[((size_t)b * log_cap + h0) * 5 + i] = src[i];
     }
@@ -1716,13 +1801,13 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
         if (best_h >= 0) {
             // among the winning hypothesis' models with equally many inliers: the first in an order
             // that does not depend on how the models were found (see model_before)
-            const double* Eh = models + ((size_t)b * hr + best_h) * kMaxModels * 9;
+            const double* Eh = models + ((size_t)b * arr_stride + arr_off + best_h) * kMaxModels * 9;
             int k0 = s_hk[best_h];
             for (int k = k0 + 1; k < s_nm[best_h]; ++k)
                 if (s_cnt[best_h * kMaxModels + k] == s_hb[best_h] && model_before(Eh + k * 9, Eh + k0 * 9)) k0 = k;
             for (int i = 0; i < 9; ++i) s.bestE[i] = Eh[k0 * 9 + i];
         }
-        if (stop < hr || h0 + hr >= s.niters || next_round <= 0) s.done = 1;
+        if (hr > 0 && (stop < hr || h0 + hr >= s.niters || final_call)) s.done = 1;   // (hr = 0: a call that only draws)
         s_stop = stop;
     }
     __syncthreads();
@@ -1736,7 +1821,7 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         if (tid == 0) s.models_scored += sum;
     }
-    int32_t* out = samples + (size_t)b * samples_stride;
+    int32_t* out = samples + (size_t)b * samples_stride + (size_t)out_off * 5;
     const bool plain = s_plain != 0;
     if (want > 0 && plain) {
         if (tid == 64) {
@@ -2152,11 +2237,11 @@ __global__ __launch_bounds__(ST) void five_point_debug_front_kernel(const double
 
 __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int count, const double* __restrict__ recs,
                                                                              double* __restrict__ models,
-                                                                             int32_t* __restrict__ nmodels) {
+                                                                             int32_t* __restrict__ nmodels, int literal) {
     __shared__ BackShared sh;
     const int h0 = blockIdx.x * HB;
     solve_back_block(sh, min(HB, count - h0), recs + (size_t)h0 * HYP_REC, models + (size_t)h0 * kMaxModels * 9,
-                     nmodels + h0);
+                     nmodels + h0, literal);
 }
 
 // Hypotheses per round.  A round solves all of its hypotheses for every pair that is still
@@ -2166,8 +2251,7 @@ __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int
 // the setting for a long time, merging its third and fourth round gains 4 % there and 3 % on a
 // 100-pair sequence (fewer launches), {32, 480, 488} gains 7 % there but makes a pair that needs
 // 80 iterations solve 512.
-static int round_size(int round, int fixed) {
-    if (fixed > 0) return 512;
+static int round_size(int round) {
     static const int sz[] = {32, 96, 384, 488};
     return round < 4 ? sz[round] : 0;
 }
@@ -2195,7 +2279,18 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     P.t2_mid = 0.5 * ((double)P.t2 + (double)std::nextafter(P.t2, std::numeric_limits<float>::infinity()));
     P.confidence = confidence;
     P.fixed_iters = fixed_iters;
-    const int HR = 512;   // largest round
+    // Largest round.  The adaptive loop works in rounds of at most 512 hypotheses (a pair stops at
+    // the end of the round in which its bound is reached, so larger rounds solve more in vain).  A
+    // fixed count has no early exit and its sample stream does not depend on any outcome: there
+    // all hypotheses are drawn first and solved and scored in one round (in several if a batch
+    // times the count exceeds 2^18 hypotheses, 600 MB of workspace), and only the bookkeeping walks
+    // it in pieces of 512 - eight launches per stage of 4096 hypotheses become one.
+    const int kChunk = UPD_MAX_HR;
+    int HR = kChunk;
+    if (fixed_iters > kChunk) {
+        const long long cap = std::max<long long>(kChunk, (262144ll / batch) / kChunk * kChunk);
+        HR = (int)std::min<long long>(((long long)fixed_iters + kChunk - 1) / kChunk * kChunk, cap);
+    }
     // the minimal solver without refinement, second chart or duplicate drop, as OpenCV runs it
     const int literal = c->opt[VO_OPT_FIVE_POINT_LITERAL];
     int rc;
@@ -2245,33 +2340,55 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if (n_max > 0)
         hipLaunchKernelGGL(normalize_kernel, dim3((n_max + 255) / 256, batch), dim3(256), 0, s, d_p1, d_p2, d_n, n_max, P,
                            m, mf);
-    int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
-    int r0 = std::min(round_size(0, fixed_iters), total);
+    const int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
+    auto round_of = [&](int round, int h0) {   // hypotheses of a round that starts at h0
+        if (h0 >= total) return 0;
+        return std::min(fixed_iters > 0 ? HR : round_size(round), total - h0);
+    };
+    auto update = [&](int h0, int hr, int arr_stride, int arr_off, int next, int out_off, bool last) {
+        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, arr_stride, arr_off,
+                           (const double*)models, (const int32_t*)nmodels, (const int32_t*)counts, samples, HR * 5, next,
+                           out_off, last ? 1 : 0, d_samples, samples_cap, retry_list);
+    };
+    // sets [from, upto) of the round that starts at h0, beyond the first piece its predecessor drew
+    auto draw_rest = [&](int h0, int hr) {
+        for (int d = kChunk; d < hr; d += kChunk) update(h0 + d, 0, hr, 0, std::min(kChunk, hr - d), d, false);
+    };
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
-                       r0, retry_list);
+                       std::min(round_of(0, 0), kChunk), retry_list);
     int h0 = 0;
     for (int round = 0; h0 < total; ++round) {
-        int hr = std::min(round_size(round, fixed_iters), total - h0);
+        const int hr = round_of(round, h0);
         if (hr <= 0) break;
-        int next = std::min(round_size(round + 1, fixed_iters), total - (h0 + hr));
-        if (next < 0) next = 0;
+        const int next = round_of(round + 1, h0 + hr);
+        draw_rest(h0, hr);
         t_begin_on(c, VO_T_RANSAC_SOLVE, s);
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
-        hipLaunchKernelGGL(solve_roots_kernel, dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0, s, st, hr, recs, roots,
-                           nroots);
-        hipLaunchKernelGGL(solve_models_kernel, dim3((hr + HBM - 1) / HBM, batch), dim3(BACK_THREADS), 0, s, st, hr, recs,
-                           (const double*)roots, (const int32_t*)nroots, models, nmodels, literal ? nullptr : retry_list,
-                           literal);
-        // Second chart for the few hypotheses with an odd number of models: small fixed grids that
-        // stride over the list (its count is zeroed again by update_kernel).  (Running this pass on
+// the root stage one wavefront per workgroup; VO_OPT_SOLVE_VARIANT = 1: one workgroup of 512
+        // lanes per 64 hypotheses (the form the second-chart pass uses) - both give the same roots
+        if (c->opt[VO_OPT_SOLVE_VARIANT] & 1)
+            hipLaunchKernelGGL((solve_roots_kernel<BACK_THREADS, HB>), dim3((hr + HB - 1) / HB, batch), dim3(BACK_THREADS), 0,
+                               s, st, hr, recs, roots, nroots);
+        else
+            hipLaunchKernelGGL(solve_roots_wave_kernel, dim3((hr + RW_H - 1) / RW_H, batch), dim3(RW_H * RW_L), 0, s, st, hr,
+                               recs, roots, nroots);
+        hipLaunchKernelGGL((solve_models_kernel<BACK_THREADS, HBM>), dim3((hr + HBM - 1) / HBM, batch), dim3(BACK_THREADS), 0,
+                           s, st, hr, recs, (const double*)roots, (const int32_t*)nroots, models, nmodels,
+                           literal ? nullptr : retry_list, literal);
+        // Second chart for the few hypotheses with an odd number of models: grids that stride over
+        // the list (its count is zeroed again by update_kernel).  (Running this pass on
         // a stream of its own beside the scoring of the first pass's models, and scoring what it
         // adds afterwards, measured no faster: the chain is short against the scoring kernel and
         // the two event hand-offs per round cost what the overlap gains.)
         if (c->opt[VO_OPT_SECOND_CHART] && !literal) {
-            hipLaunchKernelGGL(retry_front_kernel, dim3(256), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
+            // (a workgroup per 64 list entries if every tenth hypothesis is on the list - more than
+            // measured on any scene -, at least 64; workgroups beyond the list return at once)
+            const int retry_front_wgs = std::min(8192, std::max(256, (int)(((long long)batch * hr / 10 + ST - 1) / ST)));
+            const int retry_wgs = std::min(2048, std::max(64, (int)(((long long)batch * hr / 10 + HB - 1) / HB)));
+            hipLaunchKernelGGL(retry_front_kernel, dim3(retry_front_wgs), dim3(ST), 0, s, m, nm, samples, HR * 5, hr,
                                (const int32_t*)retry_list, recs);
-            hipLaunchKernelGGL(retry_back_kernel, dim3(64), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
+            hipLaunchKernelGGL(retry_back_kernel, dim3(retry_wgs), dim3(BACK_THREADS), 0, s, (const int32_t*)retry_list,
                                (const double*)recs, models2, nmodels2);
             hipLaunchKernelGGL(merge_models_kernel, dim3(16), dim3(256), 0, s, (const int32_t*)retry_list, 0, models, nmodels,
                                (const double*)models2, (const int32_t*)nmodels2);
@@ -2281,8 +2398,13 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, (const float*)mf, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         t_end_on(c, VO_T_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, models, nmodels,
-                           counts, samples, HR * 5, next, d_samples, samples_cap, retry_list);
+        // the bookkeeping, in pieces of at most 512 hypotheses; the last piece draws the first
+        // piece of the next round
+        for (int off = 0; off < hr; off += kChunk) {
+            const int piece = std::min(kChunk, hr - off);
+            const bool tail = off + piece >= hr;
+            update(h0 + off, piece, hr, off, tail ? std::min(next, kChunk) : 0, 0, tail && next <= 0);
+        }
         h0 += hr;
     }
     hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(4 * FIN_T), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
@@ -2401,16 +2523,19 @@ extern "C" int vo_debug_five_point(vo_ctx* c, const double* x1, const double* x2
     if ((rc = ensure(c, c->r_nmodels2, (size_t)count * 4))) return rc;
     hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
                        d_in + (size_t)count * 10, count, (double*)c->r_best.p, (const int32_t*)nullptr);
+    const int literal = c->opt[VO_OPT_FIVE_POINT_LITERAL];
     hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream, count,
-                       (const double*)c->r_best.p, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p);
+                       (const double*)c->r_best.p, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p, literal);
     // the second-chart pass for odd model counts, as in the RANSAC rounds
-    hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
-                       d_in + (size_t)count * 10, count, (double*)c->r_best.p, (const int32_t*)c->r_nmodels.p);
-    hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream, count,
-                       (const double*)c->r_best.p, (double*)c->r_models2.p, (int32_t*)c->r_nmodels2.p);
-    hipLaunchKernelGGL(merge_models_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, (const int32_t*)nullptr,
-                       count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p, (const double*)c->r_models2.p,
-                       (const int32_t*)c->r_nmodels2.p);
+    if (!literal && c->opt[VO_OPT_SECOND_CHART]) {
+        hipLaunchKernelGGL(five_point_debug_front_kernel, dim3((count + ST - 1) / ST), dim3(ST), 0, c->stream, d_in,
+                           d_in + (size_t)count * 10, count, (double*)c->r_best.p, (const int32_t*)c->r_nmodels.p);
+        hipLaunchKernelGGL(five_point_debug_back_kernel, dim3((count + HB - 1) / HB), dim3(BACK_THREADS), 0, c->stream,
+                           count, (const double*)c->r_best.p, (double*)c->r_models2.p, (int32_t*)c->r_nmodels2.p, 0);
+        hipLaunchKernelGGL(merge_models_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream,
+                           (const int32_t*)nullptr, count, (double*)c->r_models.p, (int32_t*)c->r_nmodels.p,
+                           (const double*)c->r_models2.p, (const int32_t*)c->r_nmodels2.p);
+    }
     VO_HIP(c, hipGetLastError());
     VO_HIP(c, hipMemcpyAsync(Es, c->r_models.p, out_b, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(n_models, c->r_nmodels.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
