@@ -107,12 +107,21 @@ def _gen_pair(args):
     return synth.frame_pair(seed, height=h, width=w)
 
 
+def _gen_sequence(args):
+    from visual_odometry_amd import synth
+    seed, n, h, w = args
+    return synth.sequence(seed, n, height=h, width=w)
+
+
 def make_frames(cfg, rank, n_distinct, sparse):
     """Distinct synthetic frames of the workload: 2 * n_distinct for pair workloads (generated on
     the host cores in parallel, before anything touches the GPU), pairs + 1 for a sequence."""
     from visual_odometry_amd import synth
-    if cfg["sequence"]:
-        return synth.sequence(0x5EED0000 + 1000 * rank, cfg["pairs"] + 1, height=cfg["h"], width=cfg["w"])
+    if cfg["sequence"]:   # two sequences (the steps alternate between them), each generated serially
+        seeds = [(0x5EED0000 + 1000 * rank + 500 * k, cfg["pairs"] + 1, cfg["h"], cfg["w"]) for k in range(2)]
+        with concurrent.futures.ProcessPoolExecutor(2) as pool:
+            a, b = list(pool.map(_gen_sequence, seeds))
+        return a + b
     jobs = [(0x5EED0000 + 100000 * rank + p, cfg["h"], cfg["w"], sparse) for p in range(n_distinct)]
     workers = max(1, min(16, os.cpu_count() or 1, n_distinct))
     if workers == 1:
@@ -121,6 +130,28 @@ def make_frames(cfg, rank, n_distinct, sparse):
         with concurrent.futures.ProcessPoolExecutor(workers) as pool:
             pairs = list(pool.map(_gen_pair, jobs, chunksize=max(1, n_distinct // (4 * workers))))
     return [f for ab in pairs for f in ab]
+
+
+KERNELS_OF_GROUP = {"resize": ["resize_kernel"], "fast": ["fast_kernel<1>", "fast_kernel<0>"],
+                    "select": ["select_a_kernel", "harris_kernel", "select_b_kernel"], "blur": ["blur_kernel"],
+                    "describe": ["describe_kernel", "orient_kernel"], "knn2": ["knn2_bcast_kernel"], "ratio": ["ratio_kernel"],
+                    "ransac_solve": ["solve_front_kernel", "solve_roots_wave_kernel", "solve_models_kernel"],
+                    "ransac_score": ["score_kernel"], "ransac_other": ["update_kernel", "finish_kernel"]}
+
+
+def measured_issue(workload, pairs, group):
+    """Share of the GPU's vector-ALU issue slots the group's kernels fill while they run
+    (SQ_INSTS_VALU x 4 cycles over SIMD cycles of the dispatch), from the committed counter
+    passes, per kernel; None when they were taken on another configuration."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+    except OSError:
+        return None
+    if rec.get("workload") != workload or rec.get("pairs_per_step") != pairs:
+        return None
+    got = {k: rec["kernels"][k]["valu_issue_frac"] for k in KERNELS_OF_GROUP.get(group, [])
+           if k in rec.get("kernels", {}) and "valu_issue_frac" in rec["kernels"][k]}
+    return got or None
 
 
 def cpu_model():
@@ -211,14 +242,24 @@ class Runner:
         self.torch, self.dist, self.capi, self.ctxs, self.cfg, self.P, self.K, self.world = \
             torch, dist, capi, ctxs, cfg, P, K, world
         H, W = cfg["h"], cfg["w"]
+        # Two image batches of different content, used alternately by consecutive steps, so that a
+        # step never finds the previous step's input in the 256 MB Infinity Cache.  (`frames` holds
+        # material for both when the caller generated enough: 2 (P + 1) frames of two sequences,
+        # or 4 n_distinct frames of pair workloads; with less, the second batch is the first.)
         if cfg["sequence"]:
             self.n_images = P + 1
-            stack = np.stack(frames[: P + 1])
+            stacks = [np.stack(frames[: P + 1])]
+            if len(frames) >= 2 * (P + 1):
+                stacks.append(np.stack(frames[P + 1: 2 * (P + 1)]))
         else:
-            n_distinct = len(frames) // 2
             self.n_images = 2 * P
-            stack = np.stack([frames[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)])
-        self.imgs = torch.from_numpy(stack).cuda()
+            halves = [frames] if len(frames) < 4 or (len(frames) // 2) % 2 else [frames[: len(frames) // 2], frames[len(frames) // 2:]]
+            stacks = []
+            for part in halves:
+                n_distinct = len(part) // 2
+                stacks.append(np.stack([part[2 * (p % n_distinct) + k] for p in range(P) for k in range(2)]))
+        self.batches = [torch.from_numpy(st).cuda() for st in stacks]
+        self.imgs = self.batches[0]
         # two record buffers per context, used alternately: a context runs the tails of two
         # consecutive calls side by side unless they write the same records
         self.ress = [torch.zeros(P * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -227,18 +268,19 @@ class Runner:
         self.H, self.W = H, W
         self.scene_counters = True
 
-    def call(self, ctx, res):
+    def call(self, ctx, res, imgs=None):
         c = self.cfg
         fn = ctx.pipeline_sequence_dev if c["sequence"] else ctx.pipeline_pairs_dev
         n = self.P + 1 if c["sequence"] else self.P
-        fn(self.imgs.data_ptr(), n, self.H, self.W, self.W, self.H * self.W, c["nfeat"], 0.75, self.K, 1.0, 0.999,
-           c["fixed"], res.data_ptr())
+        fn((self.imgs if imgs is None else imgs).data_ptr(), n, self.H, self.W, self.W, self.H * self.W, c["nfeat"], 0.75,
+           self.K, 1.0, 0.999, c["fixed"], res.data_ptr())
 
     def step(self):
         k = self.counter % len(self.ctxs)
         r = self.counter % len(self.ress)
+        imgs = self.batches[self.counter % len(self.batches)]
         self.counter += 1
-        self.call(self.ctxs[k], self.ress[r])
+        self.call(self.ctxs[k], self.ress[r], imgs)
 
     def fence(self):
         for c in self.ctxs:
@@ -327,6 +369,7 @@ def roofline_of(group, work_per_step, avg_ms, launches, steps, workload, P):
             "valu_fp64": "algorithmic_flops_per_launch", "valu_fp32": "algorithmic_flops_per_launch"}[bound]
     return {"bound": bound, "kernel": KERNEL_OF_GROUP[group], "achieved": achieved, "peak": peak, "unit": unit,
             "frac": achieved / peak, "traffic": measured_traffic(workload, P, group) if bound == "hbm" else None,
+            "valu_issue_frac": measured_issue(workload, P, group),
             "avg_launch_ms": avg_ms, "launches_timed": launches, "launches_per_step": per_step, what: per_launch}
 
 
@@ -364,6 +407,8 @@ def main():
     ap.add_argument("--no-sequence", action="store_true")
     ap.add_argument("--no-aux-scene", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short legs on the configurations other than --workload")
     ap.add_argument("--no-scene-counters", action="store_true",
                     help="skip the one call that counts pretest passes / corners with global atomics (its FAST "
                          "launches are several times slower than normal ones and would skew per-kernel averages "
@@ -381,10 +426,17 @@ def main():
     P = cfg["pairs"] if cfg["sequence"] else (args.pairs or cfg["pairs"])
     n_distinct = P if cfg["sequence"] else max(1, min(args.distinct or P, P))
     # synthetic frames first (worker processes), the GPU runtime afterwards
-    frames = make_frames(cfg, rank, n_distinct, args.scene == "sparse")
+    # (twice the distinct pairs of a step: consecutive steps alternate between two batches)
+    frames = make_frames(cfg, rank, 2 * n_distinct, args.scene == "sparse")
     aux_frames = None
     if not args.no_aux_scene and not cfg["sequence"] and args.scene == "dense":
         aux_frames = make_frames(cfg, rank, min(64, P), True)
+    # the other configurations, measured in short legs after the headline one
+    other = {}
+    if not args.no_configs and args.scene == "dense":
+        for name, ocfg in WORKLOADS.items():
+            if name != args.workload:
+                other[name] = make_frames(ocfg, rank, 2 * ocfg["pairs"], False)
 
     import torch   # before the HIP library: one HIP runtime for both
     import torch.distributed as dist
@@ -426,7 +478,8 @@ def main():
         "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": args.workload, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct,
+        "config": {"workload": args.workload, "pairs_per_step_per_gpu": P, "distinct_pairs": 2 * n_distinct,
+                   "image_batches_rotated": len(run.batches),
                    "scene": args.scene, "mode": "consecutive frames of a sequence, each detected once"
                    if cfg["sequence"] else "independent pairs, both images of every pair detected",
                    "image": f"{W}x{H}", "max_features": nfeat, "ratio": 0.75,
@@ -622,6 +675,40 @@ def main():
                                          "not the headline metric, which detects both images of every pair"}
         del seq, res_seq
 
+    if other:
+        # Every other configuration of the benchmark in a short leg of its own: warm-up, the serial
+        # profile pass that picks the dominant kernel group, five timed steps bracketed like the
+        # headline's.  `value` above stays the headline configuration's.
+        line["configs"] = {}
+        for name, ofr in other.items():
+            ocfg = WORKLOADS[name]
+            oK = synth.default_K(ocfg["w"], ocfg["h"])
+            leg = Runner(torch, dist, capi, ctxs, ocfg, ofr, ocfg["pairs"], oK, world)
+            for _ in range(2):
+                leg.step()
+            leg.fence()
+            o_ms, o_stats = leg.profile(reps=2)
+            o_out = leg.results()
+            o_work = algorithmic_work(ocfg["h"], ocfg["w"], leg.n_images, o_out, o_stats)
+            o_dom = max(o_work, key=lambda g: o_ms[g])
+            o_steps = 20 if ocfg["sequence"] else 5   # (a step of the 100-pair sequence is well under a millisecond)
+            o_dt, o_avg, o_n = leg.timed(o_steps, o_dom)
+            o_out = leg.results()
+            line["configs"][name] = {
+                "value": ocfg["pairs"] * o_steps * world / o_dt, "unit": "frame-pairs/s",
+                "ms_per_step": 1e3 * o_dt / o_steps, "steps": o_steps, "pairs_per_step_per_gpu": ocfg["pairs"],
+                "image": f"{ocfg['w']}x{ocfg['h']}", "max_features": ocfg["nfeat"],
+                "ransac": "adaptive<=1000" if ocfg["fixed"] == 0 else f"fixed {ocfg['fixed']}",
+                "mode": "consecutive frames of a sequence, each detected once" if ocfg["sequence"]
+                else "independent pairs, both images of every pair detected",
+                "dominant_group": o_dom,
+                "roofline": roofline_of(o_dom, o_work, o_avg, o_n, o_steps, name, ocfg["pairs"]),
+                "kernel_group_ms_per_step_single_stream": o_ms,
+                "mean_matches": float(np.mean(o_out["n_matches"])), "mean_inliers": float(np.mean(o_out["inliers"])),
+                "valid_fraction": float(np.mean(o_out["valid"])), "mean_ransac_iters": float(np.mean(o_out["ransac_iters"]))}
+            del leg
+        other.clear()
+
     if not args.no_hamming:
         # second half of the metric: brute-force Hamming kNN(2), 65 536 x 65 536 descriptors.  Query
         # rows are sharded over the ranks in contiguous blocks (sharding.block_range), the train set
@@ -635,31 +722,50 @@ def main():
         idx = torch.empty((e - b, 2), dtype=torch.int32, device="cuda")
         dst = torch.empty((e - b, 2), dtype=torch.int32, device="cuda")
 
+        # The search is enqueued on the context's stream and the gather right behind it on the same
+        # stream (torch's collectives order themselves after the current stream): no host wait in
+        # between; a repetition's device time is taken with events on that stream.
+        main_stream = torch.cuda.ExternalStream(ctx.stream)
+
         def gpu_knn2(q_rows, t_rows):
             ctx.hamming_knn2_dev(q_rows.data_ptr(), q_rows.shape[0], t_rows.data_ptr(), t_rows.shape[0],
                                  idx.data_ptr(), dst.data_ptr())
-            ctx.sync()
             return idx, dst
 
-        for _ in range(2):
-            table = sharding.sharded_knn2(gpu_knn2, q_all, tr)
-        run.fence()
-        reps = 5
-        ctx.set_timing(True, groups=["knn2"])
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            table = sharding.sharded_knn2(gpu_knn2, q_all, tr)   # kernel + (world > 1) the gather, every repetition
-        run.fence()
-        hd = (time.perf_counter() - t0) / reps
-        t = rank_max(torch, dist, hd)
-        hd = t
+        with torch.cuda.stream(main_stream):
+            for _ in range(2):
+                table = sharding.sharded_knn2(gpu_knn2, q_all, tr)
+            run.fence()
+            reps = 5
+            ctx.set_timing(True, groups=["knn2"])
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(main_stream)
+            for _ in range(reps):
+                table = sharding.sharded_knn2(gpu_knn2, q_all, tr)   # kernel + (world > 1) the gather, every repetition
+            ev1.record(main_stream)
+            run.fence()
+        wall = (time.perf_counter() - t0) / reps
+        hd = rank_max(torch, dist, ev0.elapsed_time(ev1) * 1e-3 / reps)
+        wall = rank_max(torch, dist, wall)
         k_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
         ctx.set_timing(False)
+        # what one of eight ranks runs: an 8 192-row block of the queries against the whole train set
+        # (too few query blocks for 256 compute units, so the library splits the train set as well)
+        shard_ms = None
+        if world == 1:
+            ctx.set_timing(True, groups=["knn2"])
+            for _ in range(5):
+                ctx.hamming_knn2_dev(q_all.data_ptr(), 8192, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+            ctx.sync()
+            shard_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
+            ctx.set_timing(False)
         alg_bytes = float(nq_total) * nt * 32
         lane_ops = KNN_LANE_OPS * nq_total * nt
         line["hamming"] = {"workload": "c4_hamming_65536x65536", "value": alg_bytes / hd / 1e9,
                            "unit": "GB/s (Nq*Nt*32 B / s)", "pair_compares_per_s": float(nq_total) * nt / hd,
-                           "ms": 1e3 * hd, "kernel_ms_rank0": k_ms, "rows_this_rank": e - b,
+                           "ms": 1e3 * hd, "host_wall_ms": 1e3 * wall, "kernel_ms_rank0": k_ms, "rows_this_rank": e - b,
+                           "shard_of_8192_rows_kernel_ms": shard_ms,
                            "table_rows_on_rank0": int(table.shape[0]) if table is not None else None,
                            "roofline": {"bound": "valu_int", "kernel": "knn2_bcast_kernel",
                                         "achieved": lane_ops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 * world,

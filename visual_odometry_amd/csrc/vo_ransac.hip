@@ -2246,14 +2246,16 @@ __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int
 
 // Hypotheses per round.  A round solves all of its hypotheses for every pair that is still
 // running, so what a pair solves beyond its final iteration count is waste; but a round is also
-// a chain of some ten launches, and small launches use the GPU badly.  Measured: eight rounds
-// of 128 lose 10 % on a scene whose counts spread over 100..1000, {32, 96, 128, 256, 488} was
-// the setting for a long time, merging its third and fourth round gains 4 % there and 3 % on a
-// 100-pair sequence (fewer launches), {32, 480, 488} gains 7 % there but makes a pair that needs
-// 80 iterations solve 512.
-static int round_size(int round) {
-    static const int sz[] = {32, 96, 384, 488};
-    return round < 4 ? sz[round] : 0;
+// a chain of some ten launches, and small launches use the GPU badly.  Measured on batches of
+// 512 pairs: eight rounds of 128 lose 10 % on a scene whose counts spread over 100..1000,
+// {32, 96, 128, 256, 488} was the setting for a long time, merging its third and fourth round
+// gains 4 % there and 3 % on a 100-pair sequence (fewer launches), finer rounds at the top
+// ({32, 96, 256, 308, 308}) lose 1.5 %.  A call on a few pairs is nothing but its launch chain -
+// five hundred five-point solves more or less do not show - so there two rounds of the largest
+// size replace four: 19 launches instead of 35 behind the matcher.
+static int round_size(int round, int batch) {
+    static const int large[] = {32, 96, 384, 488}, small[] = {512, 488, 0, 0};
+    return round < 4 ? (batch <= 32 ? small : large)[round] : 0;
 }
 
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
@@ -2343,7 +2345,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     const int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
     auto round_of = [&](int round, int h0) {   // hypotheses of a round that starts at h0
         if (h0 >= total) return 0;
-        return std::min(fixed_iters > 0 ? HR : round_size(round), total - h0);
+        return std::min(fixed_iters > 0 ? HR : round_size(round, batch), total - h0);
     };
     auto update = [&](int h0, int hr, int arr_stride, int arr_off, int next, int out_off, bool last) {
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, arr_stride, arr_off,
