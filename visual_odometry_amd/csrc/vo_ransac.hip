@@ -1715,7 +1715,7 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
     // does, and the iteration bound can only shrink during the replay - so the sets are drawn for
     // the bound as it stood before the replay; surplus sets are never used, and a pair that ends
     // in this round never looks at the stream again.
-    const int want = next_round > 0 ? min(next_round, niters0 - (h0 + hr)) : 0;
+    const int want = next_round > 0 && !exact5 ? min(next_round, niters0 - (h0 + hr)) : 0;   // (five points: the one set is the points as they come)
     // (fewer than 16 points: most sets hold repeats; more than 65535: the values do not fit 16
     // bits - both rare in practice - then one lane draws the plain way)
     const bool fast_draw = want > 0 && n >= 16 && n < 65536;
@@ -1902,6 +1902,114 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
         if (s_drawn) s.rng = s_rng;
         stv[b] = s;
     }
+}
+
+// ---- the bookkeeping of a fixed-count round
+// With a fixed hypothesis count the iteration bound never moves, so the serial loop's outcome is
+// simply the first hypothesis that reaches the round's largest inlier count (if that beats what
+// earlier rounds found and the minimum of five): every 512-hypothesis piece of the round finds
+// its own first maximum side by side (fixed_scan_kernel, a workgroup per piece and pair) and one
+// lane per pair walks the pieces in order (fixed_pick_kernel) - two launches where replaying the
+// pieces one after the other through update_kernel took eight for 4096 hypotheses.
+struct FixedPart {
+    int best;     // largest count of a model in the piece (-1: none)
+    int h;        // first hypothesis of the round that reaches it
+    int nm_sum;   // models of the piece's live hypotheses
+    int pad;
+};
+constexpr int FX_T = 256;
+__global__ __launch_bounds__(FX_T) void fixed_scan_kernel(const RState* __restrict__ stv, int h0, int hr,
+                                                         const int32_t* __restrict__ nmodels,
+                                                         const int32_t* __restrict__ counts,
+                                                         FixedPart* __restrict__ parts,
+                                                         const int32_t* __restrict__ samples, int samples_stride,
+                                                         int32_t* __restrict__ samples_log, int log_cap) {
+    __shared__ unsigned long long s_key[FX_T / 64];
+    __shared__ int s_sum[FX_T / 64];
+    const int b = blockIdx.y, piece = blockIdx.x, tid = threadIdx.x;
+    if (stv[b].done) return;   // workgroup-uniform
+    const int niters = stv[b].niters, exact5 = stv[b].exact5;
+    const int base = piece * UPD_MAX_HR;
+    const int live = min(min(UPD_MAX_HR, hr - base), max(niters - (h0 + base), 0));
+    if (samples_log) {   // the sets the loop walks, in the order drawn
+        const int32_t* src = samples + (size_t)b * samples_stride + (size_t)base * 5;
+        const int lim = min(live, log_cap - (h0 + base));
+        for (int i = tid; i < lim * 5; i += FX_T) samples_log[((size_t)b * log_cap + h0 + base) * 5 + i] = src[i];
+    }
+    // key: count + 1 in the upper half, the complement of the hypothesis index below it, so that the
+    // largest key is the largest count at the lowest index
+    unsigned long long key = 0;
+    int sum = 0;
+    for (int h = tid; h < live; h += FX_T) {
+        const size_t slot = (size_t)b * hr + base + h;
+        int nm = nmodels[slot];
+        if (exact5 && nm != 1) nm = 0;
+        sum += nm;
+        int best = -1;
+        for (int k = 0; k < nm; ++k) best = max(best, counts[slot * kMaxModels + k]);
+        const unsigned long long mine = ((unsigned long long)(uint32_t)(best + 1) << 32) | (uint32_t)(0x7FFFFFFF - (base + h));
+        key = mine > key ? mine : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+        sum += __shfl_xor(sum, o);
+    }
+    if ((tid & 63) == 0) {
+        s_key[tid >> 6] = key;
+        s_sum[tid >> 6] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < FX_T / 64; ++w) {
+            key = s_key[w] > key ? s_key[w] : key;
+            sum += s_sum[w];
+        }
+        FixedPart p;
+        p.best = (int)(uint32_t)(key >> 32) - 1;
+        p.h = 0x7FFFFFFF - (int)(uint32_t)key;
+        p.nm_sum = sum;
+        p.pad = 0;
+        parts[(size_t)b * gridDim.x + piece] = p;
+    }
+}
+
+__global__ void fixed_pick_kernel(RState* __restrict__ stv, int batch, int h0, int hr, int n_pieces,
+                                  const FixedPart* __restrict__ parts, const double* __restrict__ models,
+                                  const int32_t* __restrict__ nmodels, const int32_t* __restrict__ counts,
+                                  int final_call, int32_t* __restrict__ retry_list) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
+    if (b >= batch) return;
+    RState s = stv[b];
+    if (s.done) return;
+    const int stop = min(hr, max(s.niters - h0, 0));   // hypotheses of the round the serial loop walks
+    int cur = max(s.max_good, 4), win = -1;
+    for (int p = 0; p < n_pieces; ++p) {
+        const FixedPart q = parts[(size_t)b * n_pieces + p];
+        s.models_scored += q.nm_sum;
+        if (q.best > cur) {
+            cur = q.best;
+            win = q.h;
+        }
+    }
+    if (win >= 0) {
+        // among the winning hypothesis' models with equally many inliers: the first in an order that
+        // does not depend on how the models were found (see model_before)
+        const size_t slot = (size_t)b * hr + win;
+        const double* Eh = models + slot * kMaxModels * 9;
+        int nm = nmodels[slot];
+        if (s.exact5 && nm != 1) nm = 0;
+        int k0 = -1;
+        for (int k = 0; k < nm; ++k)
+            if (counts[slot * kMaxModels + k] == cur && (k0 < 0 || model_before(Eh + k * 9, Eh + k0 * 9))) k0 = k;
+        s.max_good = cur;
+        for (int i = 0; i < 9; ++i) s.bestE[i] = Eh[k0 * 9 + i];
+    }
+    if (stop > 0) s.iters_run = h0 + stop;
+    if (stop < hr || h0 + hr >= s.niters || final_call) s.done = 1;
+    stv[b] = s;
 }
 
 // ------------------------------------------------------------------ pose recovery
@@ -2251,10 +2359,11 @@ __global__ __launch_bounds__(BACK_THREADS) void five_point_debug_back_kernel(int
 // {32, 96, 128, 256, 488} was the setting for a long time, merging its third and fourth round
 // gains 4 % there and 3 % on a 100-pair sequence (fewer launches), finer rounds at the top
 // ({32, 96, 256, 308, 308}) lose 1.5 %.  A call on a few pairs is nothing but its launch chain -
-// five hundred five-point solves more or less do not show - so there two rounds of the largest
-// size replace four: 19 launches instead of 35 behind the matcher.
+// some hundred five-point solves more or less do not show - so there the second and third round
+// are one ({512, 488} measured slower on a pair that ends within 32 hypotheses: the kernels of a
+// 512-hypothesis round take 0.3 ms however few pairs they serve).
 static int round_size(int round, int batch) {
-    static const int large[] = {32, 96, 384, 488}, small[] = {512, 488, 0, 0};
+    static const int large[] = {32, 96, 384, 488}, small[] = {32, 480, 488, 0};
     return round < 4 ? (batch <= 32 ? small : large)[round] : 0;
 }
 
@@ -2310,6 +2419,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     if ((rc = ensure(c, c->r_nroots, (size_t)batch * HR * 4))) return rc;
     if ((rc = ensure(c, c->r_best, (size_t)batch * HR * HYP_REC * sizeof(double)))) return rc;
     if ((rc = ensure(c, c->r_counts, (size_t)batch * HR * kMaxModels * 4))) return rc;
+    if ((rc = ensure(c, c->r_mask, (size_t)batch * (HR / kChunk + 1) * sizeof(FixedPart)))) return rc;   // per piece of a fixed-count round
     {
         static std::mutex jump_mutex;
         static bool jump_loaded[64] = {};
@@ -2337,6 +2447,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     int32_t* nroots = (int32_t*)c->r_nroots.p;
     double* recs = (double*)c->r_best.p;
     int32_t* counts = (int32_t*)c->r_counts.p;
+    FixedPart* parts = (FixedPart*)c->r_mask.p;
 
     t_begin_on(c, VO_T_RANSAC, s);
     if (n_max > 0)
@@ -2353,17 +2464,20 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                            out_off, last ? 1 : 0, d_samples, samples_cap, retry_list);
     };
     // sets [from, upto) of the round that starts at h0, beyond the first piece its predecessor drew
-    auto draw_rest = [&](int h0, int hr) {
-        for (int d = kChunk; d < hr; d += kChunk) update(h0 + d, 0, hr, 0, std::min(kChunk, hr - d), d, false);
+    auto draw_rest = [&](int h0, int hr, int from) {
+        for (int d = from; d < hr; d += kChunk) update(h0 + d, 0, hr, 0, std::min(kChunk, hr - d), d, false);
     };
+    // (init_kernel draws with one lane per pair: fine for the 32 sets of the adaptive loop's first
+    // round, 170 us for 512 - a fixed-count round has all its pieces drawn by the workgroup routine)
+    const bool init_draws = fixed_iters <= 0;
     hipLaunchKernelGGL(init_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, d_n, n_max, batch, P, samples, HR * 5,
-                       std::min(round_of(0, 0), kChunk), retry_list);
+                       init_draws ? std::min(round_of(0, 0), kChunk) : 0, retry_list);
     int h0 = 0;
     for (int round = 0; h0 < total; ++round) {
         const int hr = round_of(round, h0);
         if (hr <= 0) break;
         const int next = round_of(round + 1, h0 + hr);
-        draw_rest(h0, hr);
+        draw_rest(h0, hr, round == 0 && !init_draws ? 0 : kChunk);
         t_begin_on(c, VO_T_RANSAC_SOLVE, s);
         hipLaunchKernelGGL(solve_front_kernel, dim3((hr + ST - 1) / ST, batch), dim3(ST), 0, s, st, m, nm, samples, HR * 5,
                            h0, hr, recs);
@@ -2400,12 +2514,21 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
         hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, (const float*)mf, nm, hr, models, nmodels, P.t2, P.t2_mid,
                            counts);
         t_end_on(c, VO_T_RANSAC_SCORE, s);
-        // the bookkeeping, in pieces of at most 512 hypotheses; the last piece draws the first
-        // piece of the next round
-        for (int off = 0; off < hr; off += kChunk) {
-            const int piece = std::min(kChunk, hr - off);
-            const bool tail = off + piece >= hr;
-            update(h0 + off, piece, hr, off, tail ? std::min(next, kChunk) : 0, 0, tail && next <= 0);
+        if (fixed_iters > 0 && hr > kChunk) {
+            // a large fixed-count round: every piece of 512 finds its first maximum, one lane per
+            // pair picks among them; a call that only draws fetches the next round's first piece
+            const int n_pieces = (hr + kChunk - 1) / kChunk;
+            hipLaunchKernelGGL(fixed_scan_kernel, dim3(n_pieces, batch), dim3(FX_T), 0, s, (const RState*)st, h0, hr,
+                               (const int32_t*)nmodels, (const int32_t*)counts, parts, (const int32_t*)samples, HR * 5,
+                               d_samples, samples_cap);
+            hipLaunchKernelGGL(fixed_pick_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, h0, hr, n_pieces,
+                               (const FixedPart*)parts, (const double*)models, (const int32_t*)nmodels,
+                               (const int32_t*)counts, next <= 0 ? 1 : 0, retry_list);
+            if (next > 0) update(h0 + hr, 0, hr, 0, std::min(next, kChunk), 0, false);
+        } else {
+            // the adaptive loop's replay (a round is at most 512 hypotheses), which also draws the
+            // next round's sets
+            update(h0, hr, hr, 0, std::min(next, kChunk), 0, next <= 0);
         }
         h0 += hr;
     }
