@@ -3,6 +3,7 @@ tests/test_trajectory.cpp and the image loader's contract (tests/test_image_load
 scan, rgb.txt timestamps, error strings), with the PNG/PGM decoders checked pixel by pixel
 against Pillow.  Colour-to-gray uses the BT.601 fixed-point weights; OpenCV's imread is not
 available to compare with, so that reduction is unpinned against the reference."""
+import io
 import os
 import struct
 import subprocess
@@ -119,8 +120,22 @@ def dataset(tmp_path_factory):
     for name in ("09_photo.jpg", "09a_420.jpg", "09b_444.jpeg", "09c_422.jpg", "09d_gray.jpg", "09e_optimized.jpg",
                  "09f_restart.jpg"):
         expect[name] = jpeg_luma(d / name)
-    Image.fromarray(photo).save(d / "09g_progressive.jpg", quality=80, progressive=True)
-    expect["09g_progressive.jpg"] = None   # progressive files are refused: "Failed to load image"
+    # progressive files (SOF2): spectral selection and successive approximation, DC scans interleaved,
+    # AC scans per component, with and without chroma, restart markers inside the scans
+    def save_progressive(img, name, **kw):   # (through a buffer: libjpeg cannot suspend a progressive pass on a small file buffer)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", progressive=True, **kw)
+        (d / name).write_bytes(buf.getvalue())
+    save_progressive(photo, "09g_progressive.jpg", quality=80)
+    save_progressive(photo, "09g2_prog444.jpg", quality=88, subsampling=0)   # (under Pillow's 64 KB encoder buffer)
+    save_progressive(photo[..., 1], "09g3_proggray.jpg", quality=70)
+    try:
+        save_progressive(photo, "09g4_progrestart.jpg", quality=85, subsampling=1, restart_marker_blocks=5)
+    except TypeError:
+        save_progressive(photo, "09g4_progrestart.jpg", quality=85, subsampling=1)
+    for name in ("09g_progressive.jpg", "09g2_prog444.jpg", "09g3_proggray.jpg", "09g4_progrestart.jpg"):
+        assert b"\xff\xc2" in (d / name).read_bytes()[:1000]
+        expect[name] = jpeg_luma(d / name)
     whole = (d / "09a_420.jpg").read_bytes()
     (d / "09h_truncated.jpg").write_bytes(whole[: len(whole) // 2])
     expect["09h_truncated.jpg"] = None     # a file that ends inside the entropy-coded data is refused
@@ -160,8 +175,8 @@ def test_trajectory_and_loader(dataset):
     assert stamps["00_gray8.png"] == pytest.approx(1305031102.1753, abs=1e-3)
     assert stamps["01_rgb.png"] == pytest.approx(1305031102.2112, abs=1e-3)
     assert stamps["02_gray16.png"] == 0.0
-    # the pair walk stops at the first undecodable file (the progressive JPEG, index 16)
-    assert lines[-2] == "pairs 15"
+    # the pair walk stops at the first undecodable file (the truncated JPEG, index 20)
+    assert lines[-2] == "pairs 19"
 
 
 def test_decoders_survive_damaged_files(dataset, tmp_path):

@@ -50,9 +50,22 @@ for w in ("c3", "c5", "c1", "sparse"):        # tools/profile_workload.sh runs o
         shutil.copy(os.path.join(R, f"gpurun_out/prof_{w}.json"), os.path.join(R, f"profiles/{tag}_bench_{w}.json"))
     except (IndexError, OSError) as e:
         print("no profile of", w, e)
-for w in ("c2", "c5"):                        # tools/serial_kernel_times.sh
+for w in ("c2", "c5", "sparse"):              # tools/serial_kernel_times.sh
     if os.path.exists(os.path.join(R, f"gpurun_out/serial_{w}.txt")):
         shutil.copy(os.path.join(R, f"gpurun_out/serial_{w}.txt"), os.path.join(R, f"profiles/{tag}_serial_kernel_times_{w}.txt"))
+if os.path.exists(os.path.join(R, "gpurun_out/rehearsal_2ranks.json")) and os.path.getsize(os.path.join(R, "gpurun_out/rehearsal_2ranks.json")):
+    # (gloo prints its connection notes on stdout too: keep the benchmark's line only)
+    line = [l for l in open(os.path.join(R, "gpurun_out/rehearsal_2ranks.json")) if l.startswith("{")][-1]
+    open(os.path.join(R, f"profiles/{tag}_rehearsal_2ranks_one_gpu.json"), "w").write(line)
+if glob.glob(os.path.join(R, "gpurun_out/pmc_sq_sparse/a/**/*counter_collection.csv"), recursive=True):
+    import subprocess
+    js = subprocess.run([sys.executable, os.path.join(R, "tools/pmc_sq_json.py"), os.path.join(R, "gpurun_out/pmc_sq_sparse/a"),
+                         os.path.join(R, "gpurun_out/pmc_sq_sparse/b"), str(d["config"]["pairs_per_step_per_gpu"])], check=True,
+                        capture_output=True, text=True).stdout
+    rec = json.loads(js)
+    rec["workload"] = "c2_640x480_2000kp/sparse"
+    rec["source"] = rec["source"].replace("--no-sequence)", "--no-sequence --scene sparse)")
+    json.dump(rec, open(os.path.join(R, f"profiles/{tag}_pmc_sq_sparse.json"), "w"), indent=1)
 print("bench", round(d["value"]), "pairs/s,", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "ms by events")
 for r in list(csv.DictReader(open(stats)))[:8]:
     print("  ", r["Name"][:44].ljust(44), r["Calls"], float(r["AverageNs"]) / 1e6, "ms", r["Percentage"], "%")

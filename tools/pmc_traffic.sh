@@ -9,5 +9,5 @@ mkdir -p $OUT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/calib_$c -- $GRAFT_REPO_ROOT/tools/calib_fetch
-  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $OUT/bench_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-extras --no-sequence --no-aux-scene --no-dropin --no-scene-counters
+  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d $OUT/bench_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-hamming --no-cpu-baseline --no-extras --no-sequence --no-aux-scene --no-dropin --no-scene-counters --no-configs
 done

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=$PWD
 rm -rf $R/gpurun_out/prof_serial
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-hamming --no-sequence --no-aux-scene --no-dropin --no-scene-counters --warmup 1 --steps 2 "$@" > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-hamming --no-sequence --no-aux-scene --no-dropin --no-scene-counters --no-configs --warmup 1 --steps 2 "$@" > $R/gpurun_out/prof_serial.log 2>&1 || exit 1
 python3 - $(ls $R/gpurun_out/prof_serial/*/*kernel_trace.csv | head -1) <<'PY'
 import csv, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))

@@ -237,13 +237,13 @@ class TimestampedImagePair:
 
 def read_gray_image(path):
     """8-bit grayscale of a PNG/PGM/PPM/JPEG file, reduced like the C++ loader (high byte of 16-bit
-    samples, BT.601 fixed-point weights for colour; of a sequential JPEG the luma plane as libjpeg
-    decodes it, progressive and CMYK files refused); None if it cannot be decoded."""
+    samples, BT.601 fixed-point weights for colour; of a sequential or progressive JPEG the luma plane
+    as libjpeg decodes it, CMYK files refused); None if it cannot be decoded."""
     try:
         from PIL import Image
         with Image.open(path) as im:
             if im.format == "JPEG":
-                if im.info.get("progressive") or im.mode not in ("L", "RGB"):
+                if im.mode not in ("L", "RGB"):
                     return None
                 im.draft("L", im.size)
                 import warnings

@@ -1,11 +1,15 @@
-// Grayscale decoder for baseline / extended-sequential Huffman JPEG files, for the image
-// loader (ref:src/image_loader.cpp:124 reads .jpg/.jpeg through cv::imread(IMREAD_GRAYSCALE)).
+// Grayscale decoder for baseline / extended-sequential and progressive Huffman JPEG files, for the
+// image loader (ref:src/image_loader.cpp:124 reads .jpg/.jpeg through cv::imread(IMREAD_GRAYSCALE)).
 // libjpeg, which OpenCV wraps, delivers the luma plane of a YCbCr file when asked for
 // grayscale: the chroma blocks are entropy-decoded (to stay in step with the bit stream) and
 // dropped, the luma blocks go through the integer "slow" inverse DCT that libjpeg and
 // libjpeg-turbo use by default, restated here so that the pixels are the same.
-// Progressive, arithmetic-coded, lossless, 12-bit, CMYK and Adobe-RGB files are refused (the
-// loader then reports "Failed to load image").
+// A progressive file (SOF2) is read scan by scan into a coefficient array of the luma component -
+// DC and AC bands, first passes and successive-approximation refinements as ITU-T T.81 annex G
+// defines them; scans that carry no luma are stepped over - and transformed once the last scan
+// is in (libjpeg smooths blocks only while coefficient bits are still missing, which a complete
+// file does not leave).  Arithmetic-coded, lossless, 12-bit, CMYK and Adobe-RGB files are refused
+// (the loader then reports "Failed to load image").
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -170,6 +174,11 @@ struct Decoder {
     bool have_frame = false, adobe_rgb = false;
     std::vector<uint8_t> plane;   // luma, padded to whole MCUs
     size_t plane_w = 0, plane_h = 0;
+    // progressive files: the luma coefficients (natural order, not yet dequantised) of every block
+    // of the padded plane, the luma quantisation table as it stood at the first luma scan
+    bool progressive = false, luma_quant_latched = false;
+    std::vector<int32_t> coefs;
+    uint16_t luma_quant[64] = {};
 
     explicit Decoder(std::vector<uint8_t> const& file) : f(file) {}
 
@@ -244,6 +253,7 @@ struct Decoder {
         // costs at least two code bits)
         if (plane_w * plane_h / 64 > f.size() * 8) return false;
         plane.assign(plane_w * plane_h, 0);
+        if (progressive) coefs.assign(plane_w * plane_h, 0);
         have_frame = true;
         return true;
     }
@@ -330,6 +340,169 @@ struct Decoder {
         return (size_t)(q - f.data());
     }
 
+    // ---- progressive scans (ITU-T T.81 annex G; the procedures of libjpeg's jdphuff.c)
+    struct Band {
+        int ss, se, ah, al;
+    };
+
+    // end of the entropy-coded data that starts at p: the next marker that is not a restart marker
+    size_t skip_scan(size_t p) const {
+        while (p + 1 < f.size() && !(f[p] == 0xFF && f[p + 1] != 0x00 && f[p + 1] != 0xFF && !(f[p + 1] >= 0xD0 && f[p + 1] <= 0xD7)))
+            ++p;
+        return p + 1 < f.size() ? p : 0;
+    }
+
+    // a correction bit for a coefficient that is already non-zero
+    static void refine_nonzero(BitReader& br, int32_t& c, int32_t p1) {
+        if (br.bit() && (c & p1) == 0) c += c >= 0 ? p1 : -p1;
+    }
+
+    bool ac_first(BitReader& br, Huffman const& ha, int32_t* blk, Band const& b, int& eobrun) {
+        if (eobrun > 0) {
+            --eobrun;
+            return true;
+        }
+        for (int k = b.ss; k <= b.se; ++k) {
+            int const rs = decode_symbol(br, ha);
+            if (rs < 0) return false;
+            int const r = rs >> 4, s = rs & 15;
+            if (s) {
+                k += r;
+                if (k > b.se) return false;
+                blk[kZigzag[k]] = extend(br.bits(s), s) * (1 << b.al);
+            } else if (r == 15) {
+                k += 15;
+            } else {
+                eobrun = 1 << r;
+                if (r) eobrun += br.bits(r);
+                --eobrun;
+                break;
+            }
+        }
+        return true;
+    }
+
+    bool ac_refine(BitReader& br, Huffman const& ha, int32_t* blk, Band const& b, int& eobrun) {
+        int32_t const p1 = 1 << b.al;
+        int k = b.ss;
+        if (eobrun == 0) {
+            for (; k <= b.se; ++k) {
+                int const rs = decode_symbol(br, ha);
+                if (rs < 0) return false;
+                int r = rs >> 4;
+                int32_t val = 0;
+                if (rs & 15) {
+                    if ((rs & 15) != 1) return false;   // a newly non-zero coefficient has magnitude one here
+                    val = br.bit() ? p1 : -p1;
+                } else if (r != 15) {
+                    eobrun = 1 << r;
+                    if (r) eobrun += br.bits(r);
+                    break;
+                }
+                // step over r coefficients that are still zero; those already non-zero on the way take a
+                // correction bit each
+                for (; k <= b.se; ++k) {
+                    int32_t& c = blk[kZigzag[k]];
+                    if (c != 0) refine_nonzero(br, c, p1);
+                    else if (--r < 0) break;
+                }
+                if (val) {
+                    if (k > b.se) return false;
+                    blk[kZigzag[k]] = val;
+                }
+            }
+        }
+        if (eobrun > 0) {   // the rest of the band: only correction bits
+            for (; k <= b.se; ++k) {
+                int32_t& c = blk[kZigzag[k]];
+                if (c != 0) refine_nonzero(br, c, p1);
+            }
+            --eobrun;
+        }
+        return true;
+    }
+
+    // One progressive scan that carries the luma component (index[i] == 0 for one i).
+    size_t decode_scan_progressive(size_t p, int ns, int const* index, Band const& b) {
+        BitReader br{f.data() + p, f.data() + f.size()};
+        for (int i = 0; i < ns; ++i) comp[index[i]].pred = 0;
+        size_t const bw = plane_w / 8;   // blocks per row of the coefficient array
+        size_t mcux, mcuy;
+        if (ns == 1) {
+            Component const& c = comp[index[0]];
+            size_t const cw = ((size_t)width * (size_t)c.h + (size_t)hmax - 1) / (size_t)hmax;
+            size_t const ch = ((size_t)height * (size_t)c.v + (size_t)vmax - 1) / (size_t)vmax;
+            mcux = (cw + 7) / 8;
+            mcuy = (ch + 7) / 8;
+        } else {
+            mcux = plane_w / (8 * (size_t)hmax);
+            mcuy = plane_h / (8 * (size_t)vmax);
+        }
+        int until_restart = restart, next_rst = 0, eobrun = 0;
+        auto block = [&](Component& c, bool luma, size_t bx, size_t by) -> bool {
+            int32_t dummy[64] = {};
+            int32_t* blk = luma ? &coefs[(by * bw + bx) * 64] : dummy;
+            if (b.ss == 0) {
+                if (b.ah == 0) {   // DC, first pass
+                    int const s = decode_symbol(br, dc[c.td]);
+                    if (s < 0 || s > 11) return false;
+                    if (s) c.pred += extend(br.bits(s), s);
+                    if (c.pred < -32768 || c.pred > 32767) return false;
+                    blk[0] = c.pred * (1 << b.al);
+                } else if (br.bit()) {   // DC, one more bit
+                    blk[0] |= 1 << b.al;
+                }
+                return true;
+            }
+            return b.ah == 0 ? ac_first(br, ac[c.ta], blk, b, eobrun) : ac_refine(br, ac[c.ta], blk, b, eobrun);
+        };
+        for (size_t my = 0; my < mcuy; ++my)
+            for (size_t mx = 0; mx < mcux; ++mx) {
+                if (restart && until_restart == 0) {
+                    uint8_t const* q = br.p;
+                    while (q + 2 < br.end && q[0] == 0xFF && q[1] == 0xFF) ++q;
+                    if (q + 1 >= br.end || q[0] != 0xFF || q[1] != 0xD0 + next_rst) return 0;
+                    br.p = q + 2;
+                    br.reset();
+                    next_rst = (next_rst + 1) & 7;
+                    until_restart = restart;
+                    eobrun = 0;
+                    for (int i = 0; i < ns; ++i) comp[index[i]].pred = 0;
+                }
+                for (int i = 0; i < ns; ++i) {
+                    Component& c = comp[index[i]];
+                    bool const luma = index[i] == 0;
+                    if (ns == 1) {
+                        if (!block(c, luma, mx, my)) return 0;
+                    } else {
+                        for (int v = 0; v < c.v; ++v)
+                            for (int h = 0; h < c.h; ++h)
+                                if (!block(c, luma, mx * (size_t)c.h + (size_t)h, my * (size_t)c.v + (size_t)v)) return 0;
+                    }
+                }
+                if (br.overrun) return 0;
+                if (restart) --until_restart;
+            }
+        uint8_t const* q = br.p;
+        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF)) ++q;
+        return (size_t)(q - f.data());
+    }
+
+    // all scans are in: dequantise and transform every luma block
+    void finish_progressive() {
+        size_t const bw = plane_w / 8, bh = plane_h / 8;
+        for (size_t by = 0; by < bh; ++by)
+            for (size_t bx = 0; bx < bw; ++bx) {
+                int32_t const* c = &coefs[(by * bw + bx) * 64];
+                int32_t dq[64];
+                for (int i = 0; i < 64; ++i) {
+                    int64_t const v = (int64_t)c[i] * luma_quant[i];
+                    dq[i] = (int32_t)(v < -(1 << 30) ? -(1 << 30) : v > (1 << 30) ? (1 << 30) : v);
+                }
+                idct_block(dq, &plane[by * 8 * plane_w + bx * 8], plane_w);
+            }
+    }
+
     cv::Mat run() {
         if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) return {};
         bool luma_done = false;
@@ -346,10 +519,11 @@ struct Decoder {
                 if (!read_dqt(p, e)) return {};
             } else if (m == 0xC4) {
                 if (!read_dht(p, e)) return {};
-            } else if (m == 0xC0 || m == 0xC1) {
+            } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                progressive = m == 0xC2;
                 if (!read_sof(p, e)) return {};
-            } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-                return {};   // progressive, lossless, differential or arithmetic coding
+            } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+                return {};   // lossless, differential or arithmetic coding
             } else if (m == 0xDD) {
                 if (len != 4) return {};
                 restart = (f[p] << 8) | f[p + 1];
@@ -361,22 +535,50 @@ struct Decoder {
                 int const ns = f[p];
                 if (ns < 1 || ns > ncomp || e - p < (size_t)1 + 2 * (size_t)ns + 3) return {};
                 int index[4];
+                size_t const s = p + 1 + 2 * (size_t)ns;
+                Band const band{f[s], f[s + 1], f[s + 2] >> 4, f[s + 2] & 15};
+                if (progressive) {
+                    // a DC scan covers coefficient 0 alone and may interleave components; an AC band
+                    // belongs to one component
+                    if (band.ss > band.se || band.se > 63 || band.ah > 13 || band.al > 13 || (band.ss == 0 && band.se != 0) ||
+                        (band.ss > 0 && ns != 1))
+                        return {};
+                } else if (band.ss != 0 || band.se != 63 || band.ah != 0 || band.al != 0) {
+                    return {};   // sequential: full spectrum, no approximation
+                }
+                bool has_luma = false;
                 for (int i = 0; i < ns; ++i) {
                     int const id = f[p + 1 + 2 * i], t = f[p + 2 + 2 * i];
                     int k = 0;
                     while (k < ncomp && comp[k].id != id) ++k;
                     if (k == ncomp) return {};
+                    for (int j = 0; j < i; ++j)
+                        if (index[j] == k) return {};   // a component listed twice
                     comp[k].td = t >> 4;
                     comp[k].ta = t & 15;
-                    if (comp[k].td > 3 || comp[k].ta > 3 || !dc[comp[k].td].present || !ac[comp[k].ta].present ||
-                        !have_quant[comp[k].tq])
+                    // tables a scan of this kind reads: sequential both; progressive DC first pass the DC
+                    // table, AC passes the AC table, a DC refinement none
+                    bool const need_dc = !progressive || (band.ss == 0 && band.ah == 0);
+                    bool const need_ac = !progressive || band.ss > 0;
+                    if (comp[k].td > 3 || comp[k].ta > 3 || (need_dc && !dc[comp[k].td].present) ||
+                        (need_ac && !ac[comp[k].ta].present) || !have_quant[comp[k].tq])
                         return {};
                     index[i] = k;
-                    if (k == 0) luma_done = true;
+                    if (k == 0) has_luma = true;
                 }
-                size_t const s = p + 1 + 2 * (size_t)ns;
-                if (f[s] != 0 || f[s + 1] != 63 || f[s + 2] != 0) return {};   // sequential: full spectrum, no approximation
-                size_t const next = decode_scan(e, ns, index);
+                if (has_luma) luma_done = true;
+                size_t next;
+                if (!progressive) {
+                    next = decode_scan(e, ns, index);
+                } else if (!has_luma) {
+                    next = skip_scan(e);   // chroma only: nothing of it is kept
+                } else {
+                    if (!luma_quant_latched) {
+                        std::memcpy(luma_quant, quant[comp[0].tq], sizeof(luma_quant));
+                        luma_quant_latched = true;
+                    }
+                    next = decode_scan_progressive(e, ns, index, band);
+                }
                 if (next == 0) return {};
                 pos = next;
                 continue;
@@ -384,6 +586,7 @@ struct Decoder {
             pos = e;
         }
         if (!have_frame || !luma_done) return {};
+        if (progressive) finish_progressive();
         cv::Mat img(height, width, CV_8UC1);
         for (int y = 0; y < height; ++y) std::memcpy(img.ptr<uint8_t>(y), &plane[(size_t)y * plane_w], (size_t)width);
         return img;

@@ -1846,27 +1846,35 @@ __global__ __launch_bounds__(UPD_T) void update_kernel(RState* __restrict__ stv,
             if ((tid & 63) == 0) s_w5[i >> 6] = m;
         }
         __syncthreads();
-        if (tid == 64) {   // set starts
-            int pos = 0, h = 0, word = -1;
-            unsigned long long bits = 0;
-            for (; h < want; ++h) {
-                if (pos >= R) break;
-                if ((pos >> 6) != word) {
-                    word = pos >> 6;
-                    bits = s_w5[word];
-                }
-                int nxt;
-                if ((bits >> (pos & 63)) & 1ull) nxt = pos + 5;
-                else {
+        if (tid >= 64 && tid < 128) {
+            // Set starts, by the second wavefront.  Nearly every set is five distinct draws in a row,
+            // so the starts run on in steps of five: lane j tests the set that starts 5 j draws on, the
+            // leading run of regular ones is taken in one go, and only a set with a repeat (one in
+            // n / 10) is walked by the rejection loop - some ten passes for 512 sets where one lane
+            // stepped through them one by one (25 us of the kernel's 70).
+            const int lane = tid - 64;
+            int pos = 0, h = 0;   // wavefront-uniform
+            while (h < want && pos < R) {
+                const int p = pos + 5 * lane;
+                const bool regular = h + lane < want && p < R && ((s_w5[p >> 6] >> (p & 63)) & 1ull);
+                const unsigned long long m = __ballot(regular);
+                const int run = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
+                if (lane < run) s_off[h + lane] = (uint16_t)p;
+                h += run;
+                pos += 5 * run;
+                if (run < 64 && h < want && pos < R) {
                     int idx[5];
-                    nxt = take_set(s_val, pos, R, idx);
+                    const int nxt = take_set(s_val, pos, R, idx);   // (every lane walks the same draws)
                     if (nxt < 0) break;   // the kept draws run out inside this set
+                    if (lane == 0) s_off[h] = (uint16_t)pos;
+                    ++h;
+                    pos = nxt;
                 }
-                s_off[h] = (uint16_t)pos;
-                pos = nxt;
             }
-            s_sets = h;
-            s_end = pos;
+            if (lane == 0) {
+                s_sets = h;
+                s_end = pos;
+            }
         }
         __syncthreads();
         const int sets = s_sets;
