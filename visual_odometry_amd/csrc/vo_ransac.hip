@@ -821,6 +821,10 @@ using RootsShared = RootsSharedT<HB>;
 constexpr int HBM = 96;           // hypotheses per workgroup of the model stage on its own: 4.4 candidates each on
                                   // average, 420 of the 512 lanes busy (64 hypotheses leave 45 % of them idle, and at
                                   // 244 registers per lane nothing else is resident to use the slots)
+// Gauss-Newton steps per refinement stage (rows: plans, selectable for measurements; each sums to
+// kPolishSteps)
+constexpr int kPolishStages = 4;
+__device__ const int8_t kPolishPlan[6][kPolishStages] = {{4, 8, 0, 0}, {2, 2, 8, 0}, {2, 1, 1, 8}, {3, 9, 0, 0}, {2, 10, 0, 0}, {2, 1, 9, 0}};
 template <int NH>
 struct ModelsShared {            // roots -> refined, distinct essential matrices
     double Ev[NH][kMaxModels][9];
@@ -829,8 +833,8 @@ struct ModelsShared {            // roots -> refined, distinct essential matrice
     uint16_t kept[NH];           // candidates that become models
     uint16_t map[NH * PIECES];   // work item -> hypothesis | index << 8
     int16_t np[NH];              // roots (candidates) of the hypothesis
-    uint16_t strag[NH * kMaxModels];   // candidates whose refinement goes into the second pass (map entries)
-    int nstrag;
+    uint16_t strag[kPolishStages][NH * kMaxModels];   // candidates still moving after a stage (map entries)
+    int nstrag[kPolishStages];
     int wsum;                    // candidates of the first 64 hypotheses
     int total;
 };
@@ -1201,18 +1205,19 @@ __global__ __launch_bounds__(RW_H * RW_L, 6) void solve_roots_wave_kernel(const 
 template <int NH, int T>   // T: threads of the workgroup (at least 128, see number_items_wide)
 __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, const double* __restrict__ rec0,
                                              const double* roots, int roots_stride, double* __restrict__ Es0,
-                                             int32_t* __restrict__ nm0, int literal) {
+                                             int32_t* __restrict__ nm0, int literal, int plan = 0) {
     const int tid = threadIdx.x;
     // ---- one lane per candidate: start values, refinement, acceptance
     number_items_wide<NH>(sh);
     const int total = sh.total;
-    // Refinement in two passes: nearly every candidate converges within kFirstSteps steps, but
-    // one in a few dozen does not (a spurious root wanders until the step budget is spent), and
-    // a wavefront runs as long as its slowest lane.  Candidates still moving after the first pass
-    // are collected (their (x,y,z) parked in the model slot they will fill) and finished by
-    // densely packed lanes.
-    constexpr int kFirstSteps = 4;
-    if (tid == 0) sh.nstrag = 0;
+    // Refinement in stages: a wavefront runs as long as its slowest lane, most candidates have
+    // converged after two Gauss-Newton steps (the start values come from roots good to ten digits),
+    // some need one or two more, and one in a few dozen wanders until the budget of twelve is
+    // spent (a spurious root).  After each stage the candidates still moving are collected (their
+    // (x,y,z) parked in the model slot they will fill) and the next stage runs them on densely
+    // packed lanes; polish_steps can be resumed, so the outcome is that of one uninterrupted run.
+    const int8_t* const stage_steps = kPolishPlan[plan];
+    if (tid < kPolishStages) sh.nstrag[tid] = 0;
     __syncthreads();
     for (int item = tid; item < total; item += T) {
         const int h = sh.map[item] & 0xFF, r = sh.map[item] >> 8;
@@ -1229,7 +1234,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
-            if (literal || polish_steps(EE, sx, sy, z1, kFirstSteps)) {
+            if (literal || polish_steps(EE, sx, sy, z1, stage_steps[0])) {
                 double res = polish_finish(EE, sx, sy, z1, Ev);
                 acc = literal ? res < 1e299 : res <= 1e-12;   // settled on a solution
                 if (acc) {
@@ -1240,27 +1245,39 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
                 sh.Ev[h][r][0] = sx;
                 sh.Ev[h][r][1] = sy;
                 sh.Ev[h][r][2] = z1;
-                sh.strag[atomicAdd(&sh.nstrag, 1)] = sh.map[item];
+                sh.strag[0][atomicAdd(&sh.nstrag[0], 1)] = sh.map[item];
             }
         }
         sh.acc[h][r] = acc ? 1 : 0;
     }
-    __syncthreads();
-    const int nstrag = sh.nstrag;
-    for (int i = tid; i < nstrag; i += T) {
-        const int h = sh.strag[i] & 0xFF, r = sh.strag[i] >> 8;
-        const double* rec = rec0 + (size_t)h * HYP_REC;
-        double EE[4][9], Ev[9];
+    for (int st = 1; st < kPolishStages; ++st) {
+        if (stage_steps[st] == 0) break;   // workgroup-uniform
+        __syncthreads();
+        const bool last = st + 1 == kPolishStages || stage_steps[st + 1] == 0;
+        const int n_left = sh.nstrag[st - 1];
+        for (int i = tid; i < n_left; i += T) {
+            const uint16_t entry = sh.strag[st - 1][i];
+            const int h = entry & 0xFF, r = entry >> 8;
+            const double* rec = rec0 + (size_t)h * HYP_REC;
+            double EE[4][9], Ev[9];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
-        double sx = sh.Ev[h][r][0], sy = sh.Ev[h][r][1], z1 = sh.Ev[h][r][2];
-        polish_steps(EE, sx, sy, z1, kPolishSteps - kFirstSteps);
-        if (polish_finish(EE, sx, sy, z1, Ev) <= 1e-12) {
+                for (int k = 0; k < 9; ++k) EE[t][k] = rec[51 + t * 9 + k];
+            double sx = sh.Ev[h][r][0], sy = sh.Ev[h][r][1], z1 = sh.Ev[h][r][2];
+            if (polish_steps(EE, sx, sy, z1, stage_steps[st]) || last) {
+                // (a candidate that used the whole budget is still judged by its residual)
+                if (polish_finish(EE, sx, sy, z1, Ev) <= 1e-12) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
-            sh.acc[h][r] = 1;
+                    for (int k = 0; k < 9; ++k) sh.Ev[h][r][k] = Ev[k];
+                    sh.acc[h][r] = 1;
+                }
+            } else {
+                sh.Ev[h][r][0] = sx;
+                sh.Ev[h][r][1] = sy;
+                sh.Ev[h][r][2] = z1;
+                sh.strag[st][atomicAdd(&sh.nstrag[st], 1)] = entry;
+            }
         }
     }
     __syncthreads();
@@ -1428,7 +1445,7 @@ __global__ __launch_bounds__(T) void solve_models_kernel(const RState* __restric
                                                           const int32_t* __restrict__ nroots,
                                                           double* __restrict__ models,
                                                           int32_t* __restrict__ nmodels,
-                                                          int32_t* __restrict__ retry_list, int literal) {
+                                                          int32_t* __restrict__ retry_list, int literal, int plan) {
     __shared__ ModelsShared<NH> sh;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
@@ -1437,7 +1454,7 @@ __global__ __launch_bounds__(T) void solve_models_kernel(const RState* __restric
     if (tid < NH) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
     __syncthreads();
     models_block<NH, T>(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels,
-                        models + slot * kMaxModels * 9, nmodels + slot, literal);
+                        models + slot * kMaxModels * 9, nmodels + slot, literal, plan);
     // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
     // the count it wrote itself)
     if (retry_list && tid < count && (nmodels[slot + tid] & 1))
@@ -1520,9 +1537,16 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     __syncthreads();
     if (nm == 0) return;
     int n = st[b].n;
+    // Only a hypothesis with more inliers than every earlier one changes anything, so one whose
+    // models can no longer pass what the pair had when the round began (every point still to
+    // come and every undecided test counted in its favour) is dropped: its counts stay partial,
+    // below that mark.  The counts are wave-uniform (ballots), which makes the test scalar work.
+    const int floor_cnt = max(st[b].max_good, 4);
     int cnt[kMaxModels];
 #pragma unroll
     for (int k = 0; k < kMaxModels; ++k) cnt[k] = 0;
+    int undecided = 0;   // tests ever put on the list
+    bool dropped = false;
     const double* pb = m + (size_t)b * n_max * 4;
     const float* pf = mf + (size_t)b * n_max * 4;
     constexpr float U = 5.9604645e-8f;   // 2^-24
@@ -1547,6 +1571,7 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
         if (mk == 0) return;
         if (und) q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u))] = ent;
         qn += (int)__popcll(mk);
+        undecided += (int)__popcll(mk);
     };
     static_assert(kMaxModels <= 128 && QCAP >= 2 * 128, "list entry layout and room for one iteration");
     for (int i0 = 0; i0 < n; i0 += 64) {   // (all lanes stay in the loop: the list is a wavefront's)
@@ -1579,22 +1604,28 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
             // (written so that a NaN anywhere counts as undecided)
             const bool second = 2 * pr + 1 < nm;
             const bool und0 = live && !(fabsf(r.x) > bound.x), und1 = live && second && !(fabsf(r.y) > bound.y);
-            cnt[2 * pr] += live && !und0 && r.x < 0.0f;
-            cnt[2 * pr + 1] += live && second && !und1 && r.y < 0.0f;
+            cnt[2 * pr] += (int)__popcll(__ballot(live && !und0 && r.x < 0.0f));
+            cnt[2 * pr + 1] += (int)__popcll(__ballot(live && second && !und1 && r.y < 0.0f));
             if (__any(und0 | und1)) {
                 defer(und0, ((uint32_t)(2 * pr) << 24) | (uint32_t)i);
                 defer(und1, ((uint32_t)(2 * pr + 1) << 24) | (uint32_t)i);
             }
         }
+        int top = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxModels; ++k) top = max(top, cnt[k]);
+        if (top + undecided + max(n - i0 - 64, 0) <= floor_cnt) {   // wave-uniform
+            dropped = true;
+            break;
+        }
     }
-    flush();
+    if (!dropped) flush();
+    if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < kMaxModels; ++k) {
-        if (k >= nm) break;
-        int v = cnt[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) counts[((size_t)b * hr + h) * kMaxModels + k] = v + s_extra[wave][k];
+        for (int k = 0; k < kMaxModels; ++k) {
+            if (k >= nm) break;
+            counts[((size_t)b * hr + h) * kMaxModels + k] = cnt[k] + s_extra[wave][k];
+        }
     }
 }
 
@@ -2464,7 +2495,9 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     const int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
     auto round_of = [&](int round, int h0) {   // hypotheses of a round that starts at h0
         if (h0 >= total) return 0;
-        return std::min(fixed_iters > 0 ? HR : round_size(round, batch), total - h0);
+        // (a fixed count above 512 starts with a round of 512: what that finds lets the scoring
+        // kernel drop most hypotheses of the large round part-way)
+        return std::min(fixed_iters > 0 ? (round == 0 ? kChunk : HR) : round_size(round, batch), total - h0);
     };
     auto update = [&](int h0, int hr, int arr_stride, int arr_off, int next, int out_off, bool last) {
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, arr_stride, arr_off,
@@ -2499,7 +2532,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                                recs, roots, nroots);
         hipLaunchKernelGGL((solve_models_kernel<BACK_THREADS, HBM>), dim3((hr + HBM - 1) / HBM, batch), dim3(BACK_THREADS), 0,
                            s, st, hr, recs, (const double*)roots, (const int32_t*)nroots, models, nmodels,
-                           literal ? nullptr : retry_list, literal);
+                           literal ? nullptr : retry_list, literal, std::min(c->opt[VO_OPT_SOLVE_VARIANT] >> 1, 5));
         // Second chart for the few hypotheses with an odd number of models: grids that stride over
         // the list (its count is zeroed again by update_kernel).  (Running this pass on
         // a stream of its own beside the scoring of the first pass's models, and scoring what it
