@@ -29,9 +29,10 @@ for d in sys.argv[1:3]:
     if not files:
         continue
     for r in csv.DictReader(open(files[-1])):
-        name = r["Kernel_Name"].split("(")[0].split("::")[-1].split(" ")[-1]
-        if not name.startswith("fast_kernel"):   # (fast_kernel<0> / <1> / <2> do different work: kept apart)
-            name = name.split("<")[0]
+        full = r["Kernel_Name"].split("(")[0]
+        name = full.split("<")[0].split("::")[-1].split(" ")[-1]
+        if name.startswith("fast_kernel") and "<" in full:   # (fast_kernel<0> / <1> / <2> do different work: kept apart)
+            name += "<" + full.split("<", 1)[1]
         key = (d, r["Dispatch_Id"])
         per[name][key][r["Counter_Name"]] = float(r["Counter_Value"])
         meta[key] = (int(r["Grid_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

@@ -320,6 +320,177 @@ __global__ __launch_bounds__(64 * NW) void knn2_bcast_kernel(const uint8_t* __re
     }
 }
 
+// The same search on the matrix cores.  With every bit written as +-1 the Hamming distance of two
+// 256-bit rows is (256 - dot) / 2, a 256-deep dot product, and gfx950 multiplies 4-bit floats
+// (E2M1: sign and magnitude, +-2 and +-4 are exact codes) 32 x 32 x 64 at a time with fp32
+// accumulation: a 32 x 32 tile of distances is four v_mfma_scale_f32_32x32x64_f8f6f4, about 160
+// cycles on a SIMD's matrix core, against the 16 000 vector cycles of 16 xor/popcount pairs for
+// each of its 1024 entries.  A bit becomes the sign of a nibble with three shifts and four and-ors
+// per dword (the order of the 256 positions does not matter as long as both sides use the same
+// one); train values are +-2, query values -+4 times the block scale 2^11, so a product is
+// -16384 where the bits agree and +16384 where they differ and the tile comes out as
+// 32768 d - 2^22, to which the accumulator's start value adds 2^22 + r: every result is the
+// packed key 32768 d + r itself, an integer below 2^24 and therefore exact in fp32, r being the
+// train row in a frame that moves with the tile (the running keys are aged by the rows passed).
+// What is left for the vector ALUs is one v_min_f32 and one v_med3_f32 per key.
+// A wavefront keeps two groups of 32 queries (the B operands, 32 registers) and streams the train
+// set in 32-row tiles straight from global memory, a 16-byte load per lane and tile.  C layout of
+// the instruction: lane l holds column l & 31 (the query), rows (i & 3) + 8 (i >> 2) + 4 (l >> 5)
+// in register i; operand lane l supplies row / column l & 31, positions 128 (l >> 5) .. + 127.
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+constexpr int MF_FRAME = 32704;        // r of the current tile's row 0; rows behind it count down
+constexpr int MF_CHUNK = 30720;        // train rows per chunk of one frame (a multiple of 32 * 16)
+constexpr float MF_NONE = 3.0e7f;      // above every key (2^24 and up: no row)
+constexpr int MF_SCALE_ONE = 0x7F7F7F7F, MF_SCALE_2K = 0x8A8A8A8A;   // E8M0 block scales 2^0 and 2^11
+
+// 32 bits -> 32 fp4 values of one magnitude: nibble i of dword j has bit 4 i + j as its sign
+__device__ __forceinline__ v8i32 fp4_signs(uint32_t x, uint32_t mag) {
+    v8i32 o = {(int)(((x << 3) & 0x88888888u) | mag), (int)(((x << 2) & 0x88888888u) | mag),
+               (int)(((x << 1) & 0x88888888u) | mag), (int)((x & 0x88888888u) | mag), 0, 0, 0, 0};
+    return o;
+}
+// (compiler builtins, not inline assembly: the wait states between a matrix instruction and the
+// first read of its result are put in by the compiler, which does not look inside an asm block)
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// (the minimum of two positive floats through their bit patterns: fminf brings a canonicalising
+// v_max_f32 with it)
+__device__ __forceinline__ float min2f(float a, float b) {
+    return __builtin_bit_cast(float, min(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)));
+}
+
+template <int NW>   // wavefronts per workgroup: they split the train rows and merge at the end
+__global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr,
+                                                        int cnt_stride, int nq_max, size_t q_stride,
+                                                        const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr,
+                                                        int nt_max, size_t t_stride, int32_t* __restrict__ idx2,
+                                                        int32_t* __restrict__ dist2, int rows_per_z,
+                                                        unsigned long long* __restrict__ part_out) {
+    __shared__ unsigned long long part[NW][64][2];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
+    const int nt = nt_arr ? min(nt_arr[b * cnt_stride], nt_max) : nt_max;
+    const int qbase = blockIdx.x * 64;
+    if (qbase >= nq) return;
+    const uint8_t* qb = q + (size_t)b * q_stride;
+    const uint8_t* tb = t + (size_t)b * t_stride;
+
+    // the queries: group g holds rows qbase + 32 g + col; -+4 (the flipped sign makes agreeing bits
+    // the negative product)
+    v8i32 Bq[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qi = min(qbase + 32 * g + col, nq - 1);
+        const uint4 raw = *reinterpret_cast<const uint4*>(qb + (size_t)qi * 32 + 16 * half);
+        Bq[g][0] = fp4_signs(~raw.x, 0x66666666u);
+        Bq[g][1] = fp4_signs(~raw.y, 0x66666666u);
+        Bq[g][2] = fp4_signs(~raw.z, 0x66666666u);
+        Bq[g][3] = fp4_signs(~raw.w, 0x66666666u);
+    }
+    // accumulator start values: 2^22 + the row's r in the current frame
+    v16f32 c_in;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c_in[i] = 4194304.0f + (float)(MF_FRAME + (i & 3) + 8 * (i >> 2) + 4 * half);
+
+    unsigned long long best[2][2] = {{~0ull, ~0ull}, {~0ull, ~0ull}};
+    const int t_lo = min((int)blockIdx.z * (long long)rows_per_z, (long long)nt);
+    const int t_hi = (int)min((long long)nt, (long long)t_lo + rows_per_z);
+
+    for (int cbase = t_lo; cbase < t_hi; cbase += MF_CHUNK) {
+        const int cn = min(t_hi - cbase, MF_CHUNK);
+        float k0[2] = {MF_NONE, MF_NONE}, k1[2] = {MF_NONE, MF_NONE};
+        const uint8_t* tcb = tb + (size_t)cbase * 32;
+        auto fetch = [&](int first) {   // row first + col (clamped), this lane's half of it
+            return *reinterpret_cast<const uint4*>(tcb + (size_t)min(first + col, cn - 1) * 32 + 16 * half);
+        };
+        auto tile = [&](const uint4& raw, int rows_left) {   // one 32-row tile against both query groups
+            const v8i32 A0 = fp4_signs(raw.x, 0x44444444u), A1 = fp4_signs(raw.y, 0x44444444u);
+            const v8i32 A2 = fp4_signs(raw.z, 0x44444444u), A3 = fp4_signs(raw.w, 0x44444444u);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                v16f32 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, Bq[g][0], c_in, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, Bq[g][1], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A2, Bq[g][2], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A3, Bq[g][3], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
+                if (rows_left < 32) {   // wave-uniform: rows past the end of the set get keys above all others
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if ((i & 3) + 8 * (i >> 2) + 4 * half >= rows_left) acc[i] = MF_NONE;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    k1[g] = med3f(k0[g], k1[g], acc[i]);
+                    k0[g] = min2f(k0[g], acc[i]);
+                }
+            }
+        };
+        auto age = [&](float rows) {   // the frame moves on by `rows`: rows seen so far fall behind
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                k0[g] -= rows;
+                k1[g] -= rows;
+            }
+        };
+        uint4 next;
+        int first = wave * 32, frame = first;   // this wavefront takes every NW-th 32-row tile
+        if (first < cn) next = fetch(first);
+        for (; first < cn; first += 32 * NW) {
+            const uint4 raw = next;
+            if (first + 32 * NW < cn) next = fetch(first + 32 * NW);
+            age((float)(first - frame));   // (keys that are still MF_NONE stay above 2^24)
+            frame = first;
+            tile(raw, cn - first);
+        }
+        // keys -> (distance << 32 | row); the two halves of the wavefront saw different rows
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            unsigned long long e[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float key = k == 0 ? k0[g] : k1[g];
+                const uint32_t ki = (uint32_t)key;
+                const int row = cbase + frame + (int)(ki & 32767u) - MF_FRAME;
+                e[k] = key >= 16777216.0f ? ~0ull : ((unsigned long long)(ki >> 15) << 32) | (uint32_t)row;
+            }
+            merge2(best[g][0], best[g][1], e[0], e[1]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const unsigned long long o0 = __shfl_xor(best[g][0], 32), o1 = __shfl_xor(best[g][1], 32);
+        merge2(best[g][0], best[g][1], o0, o1);
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            part[wave][32 * g + col][0] = best[g][0];
+            part[wave][32 * g + col][1] = best[g][1];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int qi = qbase + tid;
+        if (qi < nq) {
+            unsigned long long a0 = part[0][tid][0], a1 = part[0][tid][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) merge2(a0, a1, part[w][tid][0], part[w][tid][1]);
+            if (part_out) {   // split search: the chunk's two best as keys, merged by knn2_merge_kernel
+                const size_t po = (((size_t)b * gridDim.z + blockIdx.z) * nq_max + qi) * 2;
+                part_out[po] = a0;
+                part_out[po + 1] = a1;
+                return;
+            }
+            const size_t o = ((size_t)b * nq_max + qi) * 2;
+            idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
+            idx2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(uint32_t)a1;
+            dist2[o] = a0 == ~0ull ? -1 : (int32_t)(a0 >> 32);
+            dist2[o + 1] = a1 == ~0ull ? -1 : (int32_t)(a1 >> 32);
+        }
+    }
+}
+
 // A search with few query rows (one shard of a large match: 8 192 rows are 128 workgroups on 256
 // compute units) is split over the train set as well: grid.z chunks of rows_per_z train rows, each
 // workgroup leaving its chunk's two best per query as keys (distance << 32 | train row).  The keys
@@ -422,7 +593,7 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     t_begin(c, VO_T_KNN2);
     // One query per lane: the variant with the train rows in vector registers.  VO_OPT_KNN_MODE = 0
     // selects the scalar-operand kernel instead (tuning aid).
-    const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 1 : c->opt[VO_OPT_KNN_MODE];
+    const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 2 : c->opt[VO_OPT_KNN_MODE];
     if (qpl == 1 && mode >= 1) {
         // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
         // still has several to switch between.  Many (a batch of some hundred pairs): one
@@ -458,14 +629,23 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
             part = (unsigned long long*)c->k_part.p;
             grid.z = split;
         }
-#define VO_KNN_LAUNCH(NW)                                                                                              \
-    hipLaunchKernelGGL(knn2_bcast_kernel<NW>, grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, \
-                       d_nt, nt_max, t_stride, d_idx2, d_dist2, rows_per_z, part)
-        switch (nw) {
-            case 1: VO_KNN_LAUNCH(1); break;
-            case 4: VO_KNN_LAUNCH(4); break;
-            case 8: VO_KNN_LAUNCH(8); break;
-            default: VO_KNN_LAUNCH(16); break;
+#define VO_KNN_LAUNCH(KERNEL, NW)                                                                                      \
+    hipLaunchKernelGGL(KERNEL<NW>, grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max, \
+                       t_stride, d_idx2, d_dist2, rows_per_z, part)
+        if (mode >= 2) {   // the matrix-core kernel
+            switch (nw) {
+                case 1: VO_KNN_LAUNCH(knn2_mfma_kernel, 1); break;
+                case 4: VO_KNN_LAUNCH(knn2_mfma_kernel, 4); break;
+                case 8: VO_KNN_LAUNCH(knn2_mfma_kernel, 8); break;
+                default: VO_KNN_LAUNCH(knn2_mfma_kernel, 16); break;
+            }
+        } else {
+            switch (nw) {
+                case 1: VO_KNN_LAUNCH(knn2_bcast_kernel, 1); break;
+                case 4: VO_KNN_LAUNCH(knn2_bcast_kernel, 4); break;
+                case 8: VO_KNN_LAUNCH(knn2_bcast_kernel, 8); break;
+                default: VO_KNN_LAUNCH(knn2_bcast_kernel, 16); break;
+            }
         }
 #undef VO_KNN_LAUNCH
         if (split > 1)

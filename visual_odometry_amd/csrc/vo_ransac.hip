@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
                                                     const float* __restrict__ mf, int n_max, int hr,
                                                     const double* __restrict__ models,
                                                     const int32_t* __restrict__ nmodels, float t2, double t2_mid,
-                                                    int32_t* __restrict__ counts) {
+                                                    int32_t* __restrict__ counts, int h_lo, int h_hi) {
     constexpr int QCAP = 512;   // undecided tests kept per wavefront; an iteration adds at most 128
     __shared__ double sE[4][kMaxModels * 9];
     __shared__ __attribute__((aligned(8))) float sEf[4][kMaxModels / 2][9][2];   // element i of models 2p and 2p + 1
@@ -1524,8 +1524,8 @@ __global__ __launch_bounds__(256) void score_kernel(const RState* __restrict__ s
     __shared__ int s_extra[4][kMaxModels];   // inliers found among the listed tests
     int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (st[b].done) return;   // workgroup-uniform: the solve kernel wrote nothing for this pair
-    int h = blockIdx.x * 4 + wave;
-    int nm = h < hr ? nmodels[(size_t)b * hr + h] : 0;   // wave-uniform
+    int h = h_lo + blockIdx.x * 4 + wave;   // this launch scores the round's hypotheses h_lo .. h_hi - 1
+    int nm = h < h_hi ? nmodels[(size_t)b * hr + h] : 0;   // wave-uniform
     const double* Eg = models + ((size_t)b * hr + h) * kMaxModels * 9;
     for (int i = lane; i < kMaxModels * 9; i += 64) {
         const double e = i < nm * 9 ? Eg[i] : 0.0;
@@ -1962,10 +1962,11 @@ __global__ __launch_bounds__(FX_T) void fixed_scan_kernel(const RState* __restri
                                                          const int32_t* __restrict__ counts,
                                                          FixedPart* __restrict__ parts,
                                                          const int32_t* __restrict__ samples, int samples_stride,
-                                                         int32_t* __restrict__ samples_log, int log_cap) {
+                                                         int32_t* __restrict__ samples_log, int log_cap, int piece0,
+                                                         int n_pieces) {
     __shared__ unsigned long long s_key[FX_T / 64];
     __shared__ int s_sum[FX_T / 64];
-    const int b = blockIdx.y, piece = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, piece = piece0 + blockIdx.x, tid = threadIdx.x;
     if (stv[b].done) return;   // workgroup-uniform
     const int niters = stv[b].niters, exact5 = stv[b].exact5;
     const int base = piece * UPD_MAX_HR;
@@ -2010,22 +2011,24 @@ __global__ __launch_bounds__(FX_T) void fixed_scan_kernel(const RState* __restri
         p.h = 0x7FFFFFFF - (int)(uint32_t)key;
         p.nm_sum = sum;
         p.pad = 0;
-        parts[(size_t)b * gridDim.x + piece] = p;
+        parts[(size_t)b * n_pieces + piece] = p;
     }
 }
 
-__global__ void fixed_pick_kernel(RState* __restrict__ stv, int batch, int h0, int hr, int n_pieces,
+// Pieces p_lo .. p_hi - 1 of the round's n_pieces; the call with p_hi == n_pieces closes the round.
+__global__ void fixed_pick_kernel(RState* __restrict__ stv, int batch, int h0, int hr, int n_pieces, int p_lo, int p_hi,
                                   const FixedPart* __restrict__ parts, const double* __restrict__ models,
                                   const int32_t* __restrict__ nmodels, const int32_t* __restrict__ counts,
                                   int final_call, int32_t* __restrict__ retry_list) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) retry_list[0] = 0;   // the round's second-chart list has been consumed
+    const bool closes = p_hi == n_pieces;
+    if (b == 0 && closes) retry_list[0] = 0;   // the round's second-chart list has been consumed
     if (b >= batch) return;
     RState s = stv[b];
     if (s.done) return;
     const int stop = min(hr, max(s.niters - h0, 0));   // hypotheses of the round the serial loop walks
     int cur = max(s.max_good, 4), win = -1;
-    for (int p = 0; p < n_pieces; ++p) {
+    for (int p = p_lo; p < p_hi; ++p) {
         const FixedPart q = parts[(size_t)b * n_pieces + p];
         s.models_scored += q.nm_sum;
         if (q.best > cur) {
@@ -2046,8 +2049,10 @@ __global__ void fixed_pick_kernel(RState* __restrict__ stv, int batch, int h0, i
         s.max_good = cur;
         for (int i = 0; i < 9; ++i) s.bestE[i] = Eh[k0 * 9 + i];
     }
-    if (stop > 0) s.iters_run = h0 + stop;
-    if (stop < hr || h0 + hr >= s.niters || final_call) s.done = 1;
+    if (closes) {
+        if (stop > 0) s.iters_run = h0 + stop;
+        if (stop < hr || h0 + hr >= s.niters || final_call) s.done = 1;
+    }
     stv[b] = s;
 }
 
@@ -2495,9 +2500,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
     const int total = fixed_iters > 0 ? fixed_iters : kMaxIters;
     auto round_of = [&](int round, int h0) {   // hypotheses of a round that starts at h0
         if (h0 >= total) return 0;
-        // (a fixed count above 512 starts with a round of 512: what that finds lets the scoring
-        // kernel drop most hypotheses of the large round part-way)
-        return std::min(fixed_iters > 0 ? (round == 0 ? kChunk : HR) : round_size(round, batch), total - h0);
+        return std::min(fixed_iters > 0 ? HR : round_size(round, batch), total - h0);
     };
     auto update = [&](int h0, int hr, int arr_stride, int arr_off, int next, int out_off, bool last) {
         hipLaunchKernelGGL(update_kernel, dim3(batch), dim3(UPD_T), 0, s, st, batch, P, h0, hr, arr_stride, arr_off,
@@ -2551,24 +2554,35 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                                (const double*)models2, (const int32_t*)nmodels2);
         }
         t_end_on(c, VO_T_RANSAC_SOLVE, s);
-        t_begin_on(c, VO_T_RANSAC_SCORE, s);
-        hipLaunchKernelGGL(score_kernel, dim3((hr + 3) / 4, batch), dim3(256), 0, s, st, m, (const float*)mf, nm, hr, models, nmodels, P.t2, P.t2_mid,
-                           counts);
-        t_end_on(c, VO_T_RANSAC_SCORE, s);
+        auto score = [&](int lo, int hi) {
+            t_begin_on(c, VO_T_RANSAC_SCORE, s);
+            hipLaunchKernelGGL(score_kernel, dim3((hi - lo + 3) / 4, batch), dim3(256), 0, s, st, m, (const float*)mf, nm, hr,
+                               models, nmodels, P.t2, P.t2_mid, counts, lo, hi);
+            t_end_on(c, VO_T_RANSAC_SCORE, s);
+        };
         if (fixed_iters > 0 && hr > kChunk) {
-            // a large fixed-count round: every piece of 512 finds its first maximum, one lane per
-            // pair picks among them; a call that only draws fetches the next round's first piece
+            // A large fixed-count round: every piece of 512 finds its first maximum, one lane per
+            // pair picks among them.  Scoring and picking go in stages - the first pieces, then
+            // the rest - because the scoring kernel drops a hypothesis once it cannot beat what
+            // the pair already has, and within one launch it has nothing to compare with.
             const int n_pieces = (hr + kChunk - 1) / kChunk;
-            hipLaunchKernelGGL(fixed_scan_kernel, dim3(n_pieces, batch), dim3(FX_T), 0, s, (const RState*)st, h0, hr,
-                               (const int32_t*)nmodels, (const int32_t*)counts, parts, (const int32_t*)samples, HR * 5,
-                               d_samples, samples_cap);
-            hipLaunchKernelGGL(fixed_pick_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, h0, hr, n_pieces,
-                               (const FixedPart*)parts, (const double*)models, (const int32_t*)nmodels,
-                               (const int32_t*)counts, next <= 0 ? 1 : 0, retry_list);
+            const int stage_end[2] = {1, n_pieces};
+            for (int p_lo = 0, k = 0; p_lo < n_pieces; p_lo = stage_end[k++]) {
+                const int p_hi = stage_end[k];
+                score(p_lo * kChunk, std::min(p_hi * kChunk, hr));
+                hipLaunchKernelGGL(fixed_scan_kernel, dim3(p_hi - p_lo, batch), dim3(FX_T), 0, s, (const RState*)st, h0, hr,
+                                   (const int32_t*)nmodels, (const int32_t*)counts, parts, (const int32_t*)samples, HR * 5,
+                                   d_samples, samples_cap, p_lo, n_pieces);
+                hipLaunchKernelGGL(fixed_pick_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, st, batch, h0, hr, n_pieces,
+                                   p_lo, p_hi, (const FixedPart*)parts, (const double*)models, (const int32_t*)nmodels,
+                                   (const int32_t*)counts, next <= 0 ? 1 : 0, retry_list);
+            }
+            // (a call that only draws fetches the next round's first piece)
             if (next > 0) update(h0 + hr, 0, hr, 0, std::min(next, kChunk), 0, false);
         } else {
             // the adaptive loop's replay (a round is at most 512 hypotheses), which also draws the
             // next round's sets
+            score(0, hr);
             update(h0, hr, hr, 0, std::min(next, kChunk), 0, next <= 0);
         }
         h0 += hr;
