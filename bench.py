@@ -31,23 +31,23 @@ WORKLOADS = {
     "c3_kitti_1241x376_4000kp": dict(h=376, w=1241, nfeat=4000, fixed=0, pairs=256, sequence=False),
     "c5_1080p_10000kp_4096hyp": dict(h=1080, w=1920, nfeat=10000, fixed=4096, pairs=32, sequence=False),
 }
-# Ceilings (MI355X): HBM3E spec peak; vector ALUs: 256 CUs x 4 SIMDs x 32 lanes per clock at
-# 2.4 GHz = 7.86e13 lane-operations/s for 32-bit integer work, one fp64 FMA (2 flops) per lane
-# every other clock = 78.6 TFLOP/s, one packed fp32 FMA (two lanes' worth: 4 flops) per lane every
-# other clock = 157.3 TFLOP/s.
-PEAK = {"hbm": (8000.0, "GB/s"), "valu_int": (78.6, "Tlane-op/s"), "valu_fp64": (78.6, "TFLOP/s"),
+# Ceilings (MI355X): HBM3E spec peak; the matrix cores' dense fp4 peak (the matcher multiplies
+# +-1 vectors held as 4-bit floats); vector ALUs: 256 CUs x 4 SIMDs, one fp64 FMA (2 flops) per
+# lane every other clock at 2.4 GHz = 78.6 TFLOP/s, one packed fp32 FMA (two lanes' worth: 4 flops)
+# per lane every other clock = 157.3 TFLOP/s.
+PEAK = {"hbm": (8000.0, "GB/s"), "mfma": (10000.0, "TFLOP/s"), "valu_fp64": (78.6, "TFLOP/s"),
         "valu_fp32": (157.3, "TFLOP/s")}
 KERNEL_OF_GROUP = {
     "resize": "resize_kernel (chain of 7)", "fast": "fast_kernel (per launch group - level 0, levels 1-7 -: <0> on the sampled tiles, fast_raise_kernel, <1> on the other tiles, fast_check_kernel, <2> over the redo list)", "select": "select_a + harris + select_b kernels",
-    "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_bcast_kernel",
+    "blur": "blur_kernel", "describe": "orient_kernel + describe_kernel", "knn2": "knn2_mfma_kernel",
     "ratio": "ratio_kernel", "ransac_solve": "solve_front_kernel + solve_roots_kernel + solve_models_kernel (+ second-chart pass)", "ransac_score": "score_kernel",
     "ransac_other": "normalize / init / update / finish kernels",
 }
-BOUND_OF_GROUP = {"resize": "hbm", "fast": "hbm", "select": "hbm", "blur": "hbm", "describe": "hbm", "knn2": "valu_int",
+BOUND_OF_GROUP = {"resize": "hbm", "fast": "hbm", "select": "hbm", "blur": "hbm", "describe": "hbm", "knn2": "mfma",
                   "ratio": "hbm", "ransac_solve": "valu_fp64", "ransac_score": "valu_fp32", "ransac_other": "valu_fp64"}
 SAMPSON_FLOPS = 45.0          # operations of one (essential matrix, match) Sampson test (packed fp32 first, fp64 when close)
 FIVE_POINT_FLOPS = 3.0e4      # one five-point solve: null space, 10x20 elimination, degree-10 roots, polishing (estimate)
-KNN_LANE_OPS = 20.0           # per (query, train row): 8 xor + 8 popcount-accumulate + 4 for the top-2 update
+KNN_FLOPS = 512.0             # per (query, train row): a 256-deep dot product of +-1 vectors (the Hamming distance is (256 - dot) / 2)
 
 
 def level_pixels(h, w):
@@ -79,7 +79,7 @@ def algorithmic_work(h, w, n_images, out, stats):
         "select": cands * 8 + min(cands, 2.0 * kps) * (81 + 8) + kps * 8,
         "blur": n_images * 2 * sum(lv),
         "describe": min(kps * (31 * 31 + 37 * 37), n_images * 2.0 * sum(lv)) + kps * 60,
-        "knn2": KNN_LANE_OPS * float(np.sum(out["n_kp1"].astype(np.float64) * out["n_kp2"])),
+        "knn2": KNN_FLOPS * float(np.sum(out["n_kp1"].astype(np.float64) * out["n_kp2"])),
         "ratio": float(np.sum(out["n_kp1"])) * 16 + float(np.sum(out["n_matches"])) * 28,
         "ransac_solve": FIVE_POINT_FLOPS * float(np.sum(out["ransac_iters"])),
         "ransac_score": SAMPSON_FLOPS * float(np.sum(out["models_scored"].astype(np.float64) * out["n_matches"])),
@@ -134,7 +134,7 @@ def make_frames(cfg, rank, n_distinct, sparse):
 
 KERNELS_OF_GROUP = {"resize": ["resize_kernel"], "fast": ["fast_kernel<1>", "fast_kernel<0>"],
                     "select": ["select_a_kernel", "harris_kernel", "select_b_kernel"], "blur": ["blur_kernel"],
-                    "describe": ["describe_kernel", "orient_kernel"], "knn2": ["knn2_bcast_kernel"], "ratio": ["ratio_kernel"],
+                    "describe": ["describe_kernel", "orient_kernel"], "knn2": ["knn2_mfma_kernel"], "ratio": ["ratio_kernel"],
                     "ransac_solve": ["solve_front_kernel", "solve_roots_wave_kernel", "solve_models_kernel"],
                     "ransac_score": ["score_kernel"], "ransac_other": ["update_kernel", "finish_kernel"]}
 
@@ -168,19 +168,17 @@ def pair_roofline(h, w, work, pairs, step_s):
     """The pair-level bound: the time one step's algorithmic work would take on each of the three
     ceilings the path touches, and the largest of them against the measured step.  Bytes of the
     image stages per pair = 2 images x Sum(level pixels) x (FAST read + pyramid write + blur read +
-    blur write); matcher 20 lane-operations per query x train row; scoring 45 flops per model x
-    match.  The matcher term is also given at 16 lanes per clock and SIMD (3.93e13 lane-ops/s), the
-    figure a plain count of the vector ALUs gives, beside the 32 the fast instruction class reaches."""
+    blur write); matcher 512 matrix-core flops per query x train row; scoring 45 flops per model x
+    match."""
     P_px = sum(level_pixels(h, w))
     t_hbm = pairs * 2 * 4 * P_px / (PEAK["hbm"][0] * 1e9)
-    t_match = work["knn2"] / (PEAK["valu_int"][0] * 1e12)
+    t_match = work["knn2"] / (PEAK["mfma"][0] * 1e12)
     t_score = work["ransac_score"] / (PEAK["valu_fp64"][0] * 1e12)
-    terms = {"hbm": t_hbm, "valu_int": t_match, "valu_fp64": t_score}
+    terms = {"hbm": t_hbm, "mfma": t_match, "valu_fp64": t_score}
     binding = max(terms, key=terms.get)
-    return {"image_bytes_per_pair": 2 * 4 * P_px, "ms_at_hbm_peak": 1e3 * t_hbm, "ms_at_int_lane_peak": 1e3 * t_match,
-            "ms_at_int_lane_peak_16_per_clock": 2e3 * t_match, "ms_at_fp64_peak": 1e3 * t_score,
-            "binding": binding, "ms_per_step": 1e3 * step_s, "frac": terms[binding] / step_s,
-            "frac_with_16_lanes_per_clock": max(t_hbm, 2 * t_match, t_score) / step_s}
+    return {"image_bytes_per_pair": 2 * 4 * P_px, "ms_at_hbm_peak": 1e3 * t_hbm, "ms_at_fp4_matrix_peak": 1e3 * t_match,
+            "ms_at_fp64_peak": 1e3 * t_score, "binding": binding, "ms_per_step": 1e3 * step_s,
+            "frac": terms[binding] / step_s}
 
 
 def cpu_baseline(frames, K, cfg, budget_s=12.0):
@@ -365,7 +363,7 @@ def roofline_of(group, work_per_step, avg_ms, launches, steps, workload, P):
     per_launch = work_per_step[group] / max(per_step, 1e-9)
     scale = 1e9 if bound == "hbm" else 1e12
     achieved = per_launch / max(avg_ms * 1e-3, 1e-12) / scale
-    what = {"hbm": "algorithmic_bytes_per_launch", "valu_int": "algorithmic_lane_ops_per_launch",
+    what = {"hbm": "algorithmic_bytes_per_launch", "mfma": "algorithmic_flops_per_launch",
             "valu_fp64": "algorithmic_flops_per_launch", "valu_fp32": "algorithmic_flops_per_launch"}[bound]
     return {"bound": bound, "kernel": KERNEL_OF_GROUP[group], "achieved": achieved, "peak": peak, "unit": unit,
             "frac": achieved / peak, "traffic": measured_traffic(workload, P, group) if bound == "hbm" else None,
@@ -497,7 +495,8 @@ def main():
     }
     line["roofline"]["note"] = (
         "the kernel group with the largest time per step among all groups, against that group's own ceiling: HBM "
-        "bytes for the image kernels, 32-bit vector-ALU lane-operations (20 per query x train row) for the matcher, "
+        "bytes for the image kernels, fp4 matrix-core flops (512 per query x train row: the Hamming distance as a "
+        "256-deep dot product of +-1 vectors) for the matcher, "
         "fp64 vector flops (~3e4 per five-point solve) for the five-point kernels, packed fp32 vector flops (45 per "
         "model x match Sampson test, decided in single precision with a rounding bound, in fp64 when close) for the "
         "scoring kernel; "
@@ -761,20 +760,24 @@ def main():
             shard_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
             ctx.set_timing(False)
         alg_bytes = float(nq_total) * nt * 32
-        lane_ops = KNN_LANE_OPS * nq_total * nt
+        flops = KNN_FLOPS * nq_total * nt
         line["hamming"] = {"workload": "c4_hamming_65536x65536", "value": alg_bytes / hd / 1e9,
                            "unit": "GB/s (Nq*Nt*32 B / s)", "pair_compares_per_s": float(nq_total) * nt / hd,
                            "ms": 1e3 * hd, "host_wall_ms": 1e3 * wall, "kernel_ms_rank0": k_ms, "rows_this_rank": e - b,
                            "shard_of_8192_rows_kernel_ms": shard_ms,
                            "table_rows_on_rank0": int(table.shape[0]) if table is not None else None,
-                           "roofline": {"bound": "valu_int", "kernel": "knn2_bcast_kernel",
-                                        "achieved": lane_ops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 * world,
-                                        "peak": PEAK["valu_int"][0] * world, "unit": "Tlane-op/s",
-                                        "frac": lane_ops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 / PEAK["valu_int"][0],
+                           "roofline": {"bound": "mfma", "kernel": "knn2_mfma_kernel",
+                                        "achieved": flops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 * world,
+                                        "peak": PEAK["mfma"][0] * world, "unit": "TFLOP/s",
+                                        "frac": flops * (e - b) / nq_total / (k_ms * 1e-3) / 1e12 / PEAK["mfma"][0],
                                         "traffic": None,
-                                        "note": "20 lane-operations per query x train row against 32 lanes per clock "
-                                                "and SIMD; v_bcnt and every xor with a non-register operand issue at "
-                                                "half that rate, which caps this instruction mix near 0.55"},
+                                        "note": "512 flops per query x train row (a 256-deep +-1 dot product in fp4 "
+                                                "v_mfma_scale_f32_32x32x64_f8f6f4 tiles, measured at 8.3 PFLOP/s in a "
+                                                "bare stream of the instruction) against the dense fp4 peak; what "
+                                                "binds the kernel is the vector ALU issue beside the matrix "
+                                                "instructions: two operations per distance keep the two best, seven "
+                                                "per train dword turn bits into fp4 signs, and each matrix "
+                                                "instruction holds the issue port for about 18 cycles"},
                            "compulsory_hbm_bytes": (nq_total + nt) * 32 + nq_total * 16}
         del q_all, tr
 

@@ -137,11 +137,13 @@ enum {
     /* FAST with per-(image, level) raised thresholds: -1 (default) decided by
      * the batch size, 0 never, 1 always.  Environment: VO_FAST_RAISE. */
     VO_OPT_FAST_RAISE = 1,
-    /* Hamming search kernel: -1 (default) by size, 0 the scalar-operand kernel,
-     * 1 the LDS-broadcast kernel.  Environment: VO_KNN_MODE. */
+    /* Hamming search kernel: -1 (default) by size - the matrix-core kernel up to
+     * 65 536 train rows -, 0 the scalar-operand vector kernel, 1 the
+     * LDS-broadcast vector kernel, 2 the matrix-core kernel.  All give the same
+     * table.  Environment: VO_KNN_MODE. */
     VO_OPT_KNN_MODE = 2,
-    /* Wavefronts per workgroup of the LDS-broadcast kernel: 0 (default) by
-     * size, else 1, 4, 8 or 16.  Environment: VO_KNN_NW. */
+    /* Wavefronts per workgroup of the matrix-core and LDS-broadcast kernels: 0
+     * (default) by size, else 1, 4, 8 or 16.  Environment: VO_KNN_NW. */
     VO_OPT_KNN_WAVES = 3,
     /* Queries per lane of the scalar-operand kernel: 0 (default) by size, else
      * 1, 2 or 4.  Environment: VO_KNN_QPL. */

@@ -34,17 +34,22 @@ def test_knn2_matches_oracle(ctx, oracle, nq, nt):
     assert np.array_equal(gd, od)
 
 
-@pytest.mark.parametrize("knob", ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_waves=16", "knn_mode=0",
-                                  "knn_queries_per_lane=2", "knn_queries_per_lane=4", "knn_train_split=2",
-                                  "knn_train_split=5", "knn_train_split=64"])
-@pytest.mark.parametrize("nq,nt", [(1, 1), (70, 3), (300, 257), (2000, 2000), (1500, 70000)])
+@pytest.mark.parametrize("knob", ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_waves=16", "knn_mode=0", "knn_mode=1",
+                                  "knn_mode=1,knn_waves=1", "knn_mode=1,knn_waves=4", "knn_mode=1,knn_waves=8",
+                                  "knn_mode=1,knn_waves=16", "knn_queries_per_lane=2", "knn_queries_per_lane=4",
+                                  "knn_train_split=2", "knn_train_split=5", "knn_train_split=64",
+                                  "knn_mode=1,knn_train_split=5"])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (70, 3), (300, 257), (2000, 2000), (31, 4097), (1500, 70000)])
 def test_knn2_every_launch_variant(ctx, oracle, options, knob, nq, nt):
-    """The matcher picks its kernel and workgroup size from the problem size (one wavefront per
-    workgroup only for batches of several hundred pairs, the scalar-operand kernels only beyond
-    65 536 train rows): every variant is forced here, on shapes with ragged last blocks, ties at
-    distance 0 and a train set longer than one 65 536-row chunk."""
-    name, value = knob.split("=")
-    options(name, int(value))
+    """The matcher picks its kernel and workgroup size from the problem size (the matrix-core kernel
+    by default, mode 1 the vector-ALU one, one wavefront per workgroup only for batches of several
+    hundred pairs, the scalar-operand kernels only beyond 65 536 train rows): every variant is
+    forced here, on shapes with ragged last blocks, ties at distance 0, a scan long enough for the
+    matrix-core kernel's test-before-update phase with a one-row last tile (31 x 4097 with one
+    wavefront) and a train set longer than one chunk of either kernel."""
+    for part in knob.split(","):
+        name, value = part.split("=")
+        options(name, int(value))
     q = synth.descriptors(300 + nq, nq, dup_fraction=0.2)
     t = synth.descriptors(400 + nt, nt, dup_fraction=0.3)
     if nt > 100 and nq > 50:
@@ -992,7 +997,7 @@ def test_pipeline_results_do_not_depend_on_matcher_variant(ctx):
 
     want = run()
     assert np.frombuffer(want, capi.PAIR_DTYPE)["n_matches"].min() > 50
-    for knob in ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_mode=0", "knn_queries_per_lane=2",
+    for knob in ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_mode=0", "knn_mode=1", "knn_queries_per_lane=2",
                  "knn_queries_per_lane=4"]:
         name, value = knob.split("=")
         before = ctx.get_option(name)

@@ -36,20 +36,46 @@ __global__ void probe_kernel(const uint32_t* __restrict__ train, const uint32_t*
     for (int i = 0; i < 16; ++i) out[lane * 16 + i] = acc[i];
 }
 
+// NM matrix instructions (four independent accumulators) and NV independent v_med3_f32 per loop pass
+template <int NM, int NV>
 __global__ __launch_bounds__(256) void rate_kernel(int iters, float* __restrict__ out) {
     v16f acc[4];
     for (int k = 0; k < 4; ++k)
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.0f;
     v8i A = {(int)(0x22222222u ^ threadIdx.x), 0x2A2A2A2A, 0x22222222, 0x2222AAAA, 0, 0, 0, 0};
     v8i B = {0x22222222, (int)(0xA2A2A2A2u), 0x2222AA22, 0x22222222, 0, 0, 0, 0};
-    for (int it = 0; it < iters; ++it)
+    float k0[8], k1[8], x = (float)threadIdx.x;
+    for (int j = 0; j < 8; ++j) { k0[j] = 1e9f + j; k1[j] = 2e9f + j; }
+    for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            acc[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[k], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        for (int k = 0; k < NM; ++k)
+            acc[k & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[k & 3], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) k1[k & 7] = __builtin_amdgcn_fmed3f(k0[k & 7], k1[k & 7], x);
+        x += 1.0f;
+    }
     float s = 0;
     for (int k = 0; k < 4; ++k)
         for (int i = 0; i < 16; ++i) s += acc[k][i];
+    for (int j = 0; j < 8; ++j) s += k1[j];
     if (s == 12345.678f) out[0] = s;
+}
+
+template <int NM, int NV>
+void rate(const char* what, float* dout) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int iters = 2048, wgs = 2048;
+    rate_kernel<NM, NV><<<wgs, 256>>>(16, dout);
+    (void)hipEventRecord(e0);
+    rate_kernel<NM, NV><<<wgs, 256>>>(iters, dout);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    // 2048 workgroups of 4 wavefronts on 1024 SIMDs: 8 wavefronts per SIMD
+    printf("%-46s %.3f ms: %.1f cycles per loop pass and wavefront at 2.4 GHz\n", what, ms, ms * 1e-3 * 2.4e9 / (8.0 * iters));
 }
 
 int main() {
@@ -60,11 +86,11 @@ int main() {
     for (int k = 0; k < 8; ++k) q[5 * 8 + k] = t[9 * 8 + k];   // one exact match: query 5 = train 9
     uint32_t *dt, *dq;
     float* dout;
-    hipMalloc(&dt, t.size() * 4);
-    hipMalloc(&dq, q.size() * 4);
-    hipMalloc(&dout, 64 * 16 * 4);
-    hipMemcpy(dt, t.data(), t.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&dt, t.size() * 4);
+    (void)hipMalloc(&dq, q.size() * 4);
+    (void)hipMalloc(&dout, 64 * 16 * 4);
+    (void)hipMemcpy(dt, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice);
     std::vector<float> out(64 * 16);
     int bad = 0;
     for (int variant = 0; variant < 3; ++variant) {
@@ -82,28 +108,17 @@ int main() {
                 for (int k = 0; k < 8; ++k) d += __builtin_popcount(t[row * 8 + k] ^ q[col * 8 + k]);
                 const double want = 2.0 * unit * d - 256.0 * unit + c_base + reg;
                 if ((double)out[lane * 16 + reg] != want) {
-                    if (wrong < 6) printf("variant %d lane %d reg %d: got %.1f want %.1f (d %d, off by %.1f units)\n", variant, lane, reg, out[lane * 16 + reg], want, d, (out[lane * 16 + reg] - want) / unit);
+                    if (wrong < 6) printf("variant %d lane %d reg %d: got %.1f want %.1f (d %d)\n", variant, lane, reg, out[lane * 16 + reg], want, d);
                     ++wrong;
                 }
             }
         printf("fp4 mfma hamming probe, variant %d: %d of 1024 wrong\n", variant, wrong);
         bad += wrong;
     }
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    const int iters = 4096;
-    for (int wgs : {1024, 2048, 4096}) {
-        rate_kernel<<<wgs, 256>>>(16, dout);
-        hipEventRecord(e0);
-        rate_kernel<<<wgs, 256>>>(iters, dout);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms;
-        hipEventElapsedTime(&ms, e0, e1);
-        const double n = (double)wgs * 4 * iters * 4;   // wavefront instructions
-        printf("%d workgroups: %.3f ms, %.2f cycles per instruction and SIMD at 2.4 GHz, %.2f PFLOP/s\n", wgs, ms,
-               ms * 1e-3 * 2.4e9 * 1024 / n, n * 2.0 * 32 * 32 * 64 / (ms * 1e-3) / 1e15);
-    }
+    rate<8, 0>("8 matrix instructions", dout);
+    rate<0, 64>("64 v_med3_f32", dout);
+    rate<8, 64>("8 matrix instructions + 64 v_med3_f32", dout);
+    rate<8, 96>("8 matrix instructions + 96 v_med3_f32", dout);
+    rate<4, 96>("4 matrix instructions + 96 v_med3_f32", dout);
     return bad != 0;
 }

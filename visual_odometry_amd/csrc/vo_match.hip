@@ -2,17 +2,17 @@
 // gfx950.  Stands in for cv::BFMatcher(NORM_HAMMING)::knnMatch(k=2) and the
 // ratio loop of ref:src/feature_matcher.cpp:26-39.
 //
-// Integer VALU work, no MFMA: each lane keeps its query descriptor(s) (8 dwords
-// each) in registers; a train row is the same for every lane of a wavefront;
-// distance = 8 x (v_xor, v_bcnt accumulate); the running two best are kept as
-// packed keys (distance << 16 | train row) so that one v_min and one v_med3
-// update them and ties resolve to the lower train row exactly as an ascending
-// scan with a strict '<' does.  The wavefronts of a workgroup take alternate
-// 64-row runs of the train set and merge at the end.  Two kernels differ in how
-// the train row reaches the xor: knn2_bcast_kernel (one query per lane, the
-// default) broadcasts it from wavefront-private LDS into vector registers,
-// knn2_kernel<QPL> (several queries per lane, very large batches) fetches it
-// through the scalar cache and uses it as the scalar operand.
+// Three kernels compute the same table.  The default, knn2_mfma_kernel, runs the distances on the
+// matrix cores (bits as fp4 signs, see there) and leaves the vector ALUs the selection of the two
+// best.  The other two are integer vector-ALU work: each lane keeps its query descriptor(s) (8
+// dwords each) in registers, a train row is the same for every lane of a wavefront, distance =
+// 8 x (v_xor, v_bcnt accumulate); knn2_bcast_kernel (one query per lane) broadcasts the row from
+// wavefront-private LDS into vector registers, knn2_kernel<QPL> (several queries per lane, train
+// sets beyond 65 536 rows with very large grids) fetches it through the scalar cache and uses it
+// as the scalar operand.  All keep the running two best as packed keys (distance above train row)
+// so that one minimum and one median update them and ties resolve to the lower train row exactly
+// as an ascending scan with a strict '<' does.  The wavefronts of a workgroup take alternate runs
+// of the train set and merge at the end.
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
@@ -342,17 +342,25 @@ typedef float v16f32 __attribute__((ext_vector_type(16)));
 constexpr int MF_FRAME = 32704;        // r of the current tile's row 0; rows behind it count down
 constexpr int MF_CHUNK = 30720;        // train rows per chunk of one frame (a multiple of 32 * 16)
 constexpr float MF_NONE = 3.0e7f;      // above every key (2^24 and up: no row)
+constexpr int MF_LATE = 96;            // tiles of a chunk after which a wavefront tests before it updates
 constexpr int MF_SCALE_ONE = 0x7F7F7F7F, MF_SCALE_2K = 0x8A8A8A8A;   // E8M0 block scales 2^0 and 2^11
 
 // 32 bits -> 32 fp4 values of one magnitude: nibble i of dword j has bit 4 i + j as its sign
-__device__ __forceinline__ v8i32 fp4_signs(uint32_t x, uint32_t mag) {
-    v8i32 o = {(int)(((x << 3) & 0x88888888u) | mag), (int)(((x << 2) & 0x88888888u) | mag),
-               (int)(((x << 1) & 0x88888888u) | mag), (int)((x & 0x88888888u) | mag), 0, 0, 0, 0};
+// (one v_and_or_b32 per output: the mask and the magnitude are passed in registers, made opaque
+// by the caller, because a gfx9 three-operand instruction cannot carry a 32-bit literal and the
+// compiler otherwise splits every output into an and and an or)
+__device__ __forceinline__ v8i32 fp4_signs(uint32_t x, uint32_t sign_mask, uint32_t mag) {
+    v8i32 o = {(int)(((x << 3) & sign_mask) | mag), (int)(((x << 2) & sign_mask) | mag),
+               (int)(((x << 1) & sign_mask) | mag), (int)((x & sign_mask) | mag), 0, 0, 0, 0};
     return o;
 }
 // (compiler builtins, not inline assembly: the wait states between a matrix instruction and the
 // first read of its result are put in by the compiler, which does not look inside an asm block)
 __device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t ab = a < b ? a : b;
+    return ab < c ? ab : c;
+}
 // (the minimum of two positive floats through their bit patterns: fminf brings a canonicalising
 // v_max_f32 with it)
 __device__ __forceinline__ float min2f(float a, float b) {
@@ -367,8 +375,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
                                                         int32_t* __restrict__ dist2, int rows_per_z,
                                                         unsigned long long* __restrict__ part_out) {
     __shared__ unsigned long long part[NW][64][2];
+    __shared__ unsigned long long lane_best[64 * NW][2][2];   // [lane][query group][first, second]
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the loop's row counters follow from it)
     const int col = lane & 31, half = lane >> 5;
     const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
     const int nt = nt_arr ? min(nt_arr[b * cnt_stride], nt_max) : nt_max;
@@ -379,22 +389,26 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
 
     // the queries: group g holds rows qbase + 32 g + col; -+4 (the flipped sign makes agreeing bits
     // the negative product)
+    uint32_t sign_mask = 0x88888888u, mag_q = 0x66666666u, mag_t = 0x44444444u;
+    asm volatile("" : "+s"(sign_mask), "+v"(mag_q), "+v"(mag_t));   // (no instruction: keeps them out of constant folding)
     v8i32 Bq[2][4];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int qi = min(qbase + 32 * g + col, nq - 1);
         const uint4 raw = *reinterpret_cast<const uint4*>(qb + (size_t)qi * 32 + 16 * half);
-        Bq[g][0] = fp4_signs(~raw.x, 0x66666666u);
-        Bq[g][1] = fp4_signs(~raw.y, 0x66666666u);
-        Bq[g][2] = fp4_signs(~raw.z, 0x66666666u);
-        Bq[g][3] = fp4_signs(~raw.w, 0x66666666u);
+        Bq[g][0] = fp4_signs(~raw.x, sign_mask, mag_q);
+        Bq[g][1] = fp4_signs(~raw.y, sign_mask, mag_q);
+        Bq[g][2] = fp4_signs(~raw.z, sign_mask, mag_q);
+        Bq[g][3] = fp4_signs(~raw.w, sign_mask, mag_q);
     }
     // accumulator start values: 2^22 + the row's r in the current frame
     v16f32 c_in;
 #pragma unroll
     for (int i = 0; i < 16; ++i) c_in[i] = 4194304.0f + (float)(MF_FRAME + (i & 3) + 8 * (i >> 2) + 4 * half);
 
-    unsigned long long best[2][2] = {{~0ull, ~0ull}, {~0ull, ~0ull}};
+    // (the two best over the chunks done so far wait in LDS, not in eight registers of the loop)
+    unsigned long long (*best)[2] = lane_best[tid];
+    best[0][0] = best[0][1] = best[1][0] = best[1][1] = ~0ull;
     const int t_lo = min((int)blockIdx.z * (long long)rows_per_z, (long long)nt);
     const int t_hi = (int)min((long long)nt, (long long)t_lo + rows_per_z);
 
@@ -405,9 +419,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         auto fetch = [&](int first) {   // row first + col (clamped), this lane's half of it
             return *reinterpret_cast<const uint4*>(tcb + (size_t)min(first + col, cn - 1) * 32 + 16 * half);
         };
-        auto tile = [&](const uint4& raw, int rows_left) {   // one 32-row tile against both query groups
-            const v8i32 A0 = fp4_signs(raw.x, 0x44444444u), A1 = fp4_signs(raw.y, 0x44444444u);
-            const v8i32 A2 = fp4_signs(raw.z, 0x44444444u), A3 = fp4_signs(raw.w, 0x44444444u);
+        auto tile = [&](const uint4& raw, int rows_left, bool late) {   // one 32-row tile against both query groups
+            const v8i32 A0 = fp4_signs(raw.x, sign_mask, mag_t), A1 = fp4_signs(raw.y, sign_mask, mag_t);
+            const v8i32 A2 = fp4_signs(raw.z, sign_mask, mag_t), A3 = fp4_signs(raw.w, sign_mask, mag_t);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 v16f32 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, Bq[g][0], c_in, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
@@ -415,14 +429,30 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A2, Bq[g][2], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A3, Bq[g][3], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
                 if (rows_left < 32) {   // wave-uniform: rows past the end of the set get keys above all others
+                    const int lim = rows_left - 4 * half;
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if ((i & 3) + 8 * (i >> 2) + 4 * half >= rows_left) acc[i] = MF_NONE;
+                        if ((i & 3) + 8 * (i >> 2) >= lim) acc[i] = MF_NONE;
                 }
+                // Late in a long scan hardly any tile holds a row that beats a query's second best:
+                // the sixteen keys are first reduced to their minimum (eight v_min3_u32) and the
+                // thirty-two updates skipped unless some lane's minimum gets in.  Early on nearly
+                // every tile changes some lane's pair and the test would only add work.
+                bool update = true;
+                if (late) {
+                    uint32_t u[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    k1[g] = med3f(k0[g], k1[g], acc[i]);
-                    k0[g] = min2f(k0[g], acc[i]);
+                    for (int i = 0; i < 16; ++i) u[i] = __float_as_uint(acc[i]);
+                    const uint32_t m = umin3(umin3(umin3(u[0], u[1], u[2]), umin3(u[3], u[4], u[5]), umin3(u[6], u[7], u[8])),
+                                             umin3(u[9], u[10], u[11]), umin3(umin3(u[12], u[13], u[14]), u[15], u[15]));
+                    update = __ballot(m < __float_as_uint(k1[g])) != 0ull;
+                }
+                if (update) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        k1[g] = med3f(k0[g], k1[g], acc[i]);
+                        k0[g] = min2f(k0[g], acc[i]);
+                    }
                 }
             }
         };
@@ -436,12 +466,12 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         uint4 next;
         int first = wave * 32, frame = first;   // this wavefront takes every NW-th 32-row tile
         if (first < cn) next = fetch(first);
-        for (; first < cn; first += 32 * NW) {
+        for (int seen = 0; first < cn; first += 32 * NW, ++seen) {
             const uint4 raw = next;
             if (first + 32 * NW < cn) next = fetch(first + 32 * NW);
             age((float)(first - frame));   // (keys that are still MF_NONE stay above 2^24)
             frame = first;
-            tile(raw, cn - first);
+            tile(raw, cn - first, seen >= MF_LATE);
         }
         // keys -> (distance << 32 | row); the two halves of the wavefront saw different rows
 #pragma unroll
@@ -454,19 +484,20 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
                 const int row = cbase + frame + (int)(ki & 32767u) - MF_FRAME;
                 e[k] = key >= 16777216.0f ? ~0ull : ((unsigned long long)(ki >> 15) << 32) | (uint32_t)row;
             }
-            merge2(best[g][0], best[g][1], e[0], e[1]);
+            unsigned long long b0 = best[g][0], b1 = best[g][1];
+            merge2(b0, b1, e[0], e[1]);
+            best[g][0] = b0;
+            best[g][1] = b1;
         }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const unsigned long long o0 = __shfl_xor(best[g][0], 32), o1 = __shfl_xor(best[g][1], 32);
-        merge2(best[g][0], best[g][1], o0, o1);
-    }
-    if (half == 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            part[wave][32 * g + col][0] = best[g][0];
-            part[wave][32 * g + col][1] = best[g][1];
+        unsigned long long b0 = best[g][0], b1 = best[g][1];
+        const unsigned long long o0 = __shfl_xor(b0, 32), o1 = __shfl_xor(b1, 32);
+        merge2(b0, b1, o0, o1);
+        if (half == 0) {
+            part[wave][32 * g + col][0] = b0;
+            part[wave][32 * g + col][1] = b1;
         }
     }
     __syncthreads();
@@ -732,10 +763,10 @@ extern "C" int vo_match_ratio_static(vo_ctx* c, const uint8_t* d_q, int nq, cons
     int32_t* idx2 = ws;
     int32_t* dist2 = ws + (size_t)kStaticMaxQueries * 2;
     if (nq > 0) {
-        // one query per lane, train rows broadcast from LDS; four wavefronts per workgroup suit
-        // every size this entry point admits
+        // the matrix-core kernel; four wavefronts per workgroup suit every size this entry point
+        // admits
         dim3 grid((nq + 63) / 64, 1);
-        hipLaunchKernelGGL(knn2_bcast_kernel<4>, grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
+        hipLaunchKernelGGL(knn2_mfma_kernel<4>, grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
                            (const int32_t*)nullptr, nt, (size_t)0, idx2, dist2, 0x7FFFFFFF, (unsigned long long*)nullptr);
     }
     hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)idx2, (const int32_t*)dist2,
