@@ -128,7 +128,7 @@ static bool option_admits(int option, int v) {
         case VO_OPT_KNN_QUERIES_PER_LANE: return v == 0 || v == 1 || v == 2 || v == 4;
         case VO_OPT_SECOND_CHART: return v == 0 || v == 1;
         case VO_OPT_KNN_TRAIN_SPLIT: return v >= 0 && v <= 64;
-        case VO_OPT_SOLVE_VARIANT: return v >= 0 && v <= 15;
+        case VO_OPT_SOLVE_VARIANT: return v == 0 || v == 1;
         default: return false;
     }
 }

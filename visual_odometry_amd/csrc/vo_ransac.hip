@@ -821,10 +821,10 @@ using RootsShared = RootsSharedT<HB>;
 constexpr int HBM = 96;           // hypotheses per workgroup of the model stage on its own: 4.4 candidates each on
                                   // average, 420 of the 512 lanes busy (64 hypotheses leave 45 % of them idle, and at
                                   // 244 registers per lane nothing else is resident to use the slots)
-// Gauss-Newton steps per refinement stage (rows: plans, selectable for measurements; each sums to
-// kPolishSteps)
-constexpr int kPolishStages = 4;
-__device__ const int8_t kPolishPlan[6][kPolishStages] = {{4, 8, 0, 0}, {2, 2, 8, 0}, {2, 1, 1, 8}, {3, 9, 0, 0}, {2, 10, 0, 0}, {2, 1, 9, 0}};
+// Gauss-Newton steps per refinement stage (they sum to kPolishSteps; {4, 8}, {2, 2, 8}, {2, 1, 1, 8},
+// {3, 9} and {2, 10} measured within 3 % of this one, which was the fastest)
+constexpr int kPolishStages = 3;
+__device__ const int8_t kPolishPlan[kPolishStages] = {2, 1, 9};
 template <int NH>
 struct ModelsShared {            // roots -> refined, distinct essential matrices
     double Ev[NH][kMaxModels][9];
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(RW_H * RW_L, 6) void solve_roots_wave_kernel(const 
 template <int NH, int T>   // T: threads of the workgroup (at least 128, see number_items_wide)
 __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, const double* __restrict__ rec0,
                                              const double* roots, int roots_stride, double* __restrict__ Es0,
-                                             int32_t* __restrict__ nm0, int literal, int plan = 0) {
+                                             int32_t* __restrict__ nm0, int literal) {
     const int tid = threadIdx.x;
     // ---- one lane per candidate: start values, refinement, acceptance
     number_items_wide<NH>(sh);
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void models_block(ModelsShared<NH>& sh, int count, co
     // spent (a spurious root).  After each stage the candidates still moving are collected (their
     // (x,y,z) parked in the model slot they will fill) and the next stage runs them on densely
     // packed lanes; polish_steps can be resumed, so the outcome is that of one uninterrupted run.
-    const int8_t* const stage_steps = kPolishPlan[plan];
+    const int8_t* const stage_steps = kPolishPlan;
     if (tid < kPolishStages) sh.nstrag[tid] = 0;
     __syncthreads();
     for (int item = tid; item < total; item += T) {
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(T) void solve_models_kernel(const RState* __restric
                                                           const int32_t* __restrict__ nroots,
                                                           double* __restrict__ models,
                                                           int32_t* __restrict__ nmodels,
-                                                          int32_t* __restrict__ retry_list, int literal, int plan) {
+                                                          int32_t* __restrict__ retry_list, int literal) {
     __shared__ ModelsShared<NH> sh;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (st[b].done) return;
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(T) void solve_models_kernel(const RState* __restric
     if (tid < NH) sh.np[tid] = tid < count ? (int16_t)nroots[slot + tid] : (int16_t)0;
     __syncthreads();
     models_block<NH, T>(sh, count, recs + slot * HYP_REC, roots + slot * kMaxModels, kMaxModels,
-                        models + slot * kMaxModels * 9, nmodels + slot, literal, plan);
+                        models + slot * kMaxModels * 9, nmodels + slot, literal);
     // odd model count: the hypothesis goes on the list of the second-chart pass (each lane reads
     // the count it wrote itself)
     if (retry_list && tid < count && (nmodels[slot + tid] & 1))
@@ -2535,7 +2535,7 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
                                recs, roots, nroots);
         hipLaunchKernelGGL((solve_models_kernel<BACK_THREADS, HBM>), dim3((hr + HBM - 1) / HBM, batch), dim3(BACK_THREADS), 0,
                            s, st, hr, recs, (const double*)roots, (const int32_t*)nroots, models, nmodels,
-                           literal ? nullptr : retry_list, literal, std::min(c->opt[VO_OPT_SOLVE_VARIANT] >> 1, 5));
+                           literal ? nullptr : retry_list, literal);
         // Second chart for the few hypotheses with an odd number of models: grids that stride over
         // the list (its count is zeroed again by update_kernel).  (Running this pass on
         // a stream of its own beside the scoring of the first pass's models, and scoring what it
