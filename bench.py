@@ -624,6 +624,25 @@ def main():
                               "ms_per_step": 1e3 * t})
                 del rb
             line["batch_sweep"] = sweep
+            # One pair per call with the host waiting for every result (a tracking loop that needs
+            # the pose before it takes the next frame): the same buffers every call, the ordinary
+            # launch chain against the chain replayed as one HIP graph (VO_OPT_PIPELINE_GRAPH).
+            one = Runner(torch, dist, capi, [ctx], cfg, frames, 1, K, world)
+            fenced = {}
+            for graph in (0, 1):
+                ctx.set_option("pipeline_graph", graph)
+                for _ in range(5):
+                    one.call(ctx, one.ress[0])
+                    ctx.sync()
+                n_f = 200
+                t0 = time.perf_counter()
+                for _ in range(n_f):
+                    one.call(ctx, one.ress[0])
+                    ctx.sync()
+                fenced["graph_replay" if graph else "launch_chain"] = 1e3 * (time.perf_counter() - t0) / n_f
+            ctx.set_option("pipeline_graph", 0)
+            line["one_pair_fenced_call_ms"] = fenced
+            del one
 
     if aux_frames is not None:
         # The other end of the scene range: few corners, ~40 % inliers (many RANSAC rounds).  Short

@@ -137,10 +137,10 @@ enum {
     /* FAST with per-(image, level) raised thresholds: -1 (default) decided by
      * the batch size, 0 never, 1 always.  Environment: VO_FAST_RAISE. */
     VO_OPT_FAST_RAISE = 1,
-    /* Hamming search kernel: -1 (default) by size - the matrix-core kernel up to
-     * 65 536 train rows -, 0 the scalar-operand vector kernel, 1 the
-     * LDS-broadcast vector kernel, 2 the matrix-core kernel.  All give the same
-     * table.  Environment: VO_KNN_MODE. */
+    /* Hamming search kernel: -1 (default) and 2 the matrix-core kernel, 0 the
+     * scalar-operand vector kernel, 1 the LDS-broadcast vector kernel (which
+     * hands train sets beyond 65 536 rows with very large grids to the
+     * scalar-operand one).  All give the same table.  Environment: VO_KNN_MODE. */
     VO_OPT_KNN_MODE = 2,
     /* Wavefronts per workgroup of the matrix-core and LDS-broadcast kernels: 0
      * (default) by size, else 1, 4, 8 or 16.  Environment: VO_KNN_NW. */
@@ -159,7 +159,17 @@ enum {
      * hypotheses, 1 one 512-lane workgroup per 64 (tuning aid; the roots do not
      * depend on it).  Environment: VO_SOLVE_VARIANT. */
     VO_OPT_SOLVE_VARIANT = 7,
-    VO_OPT_COUNT = 8
+    /* 1: a batched pipeline call (vo_pipeline_pairs_dev / vo_pipeline_sequence_dev)
+     * that repeats the previous call's arguments exactly - same buffers, shape and
+     * parameters, as in a serving loop - is captured as a HIP graph on the context's
+     * stream and replayed from then on: one graph launch instead of the chain of
+     * some fifty kernel launches over three streams, which is what a call on a few
+     * pairs consists of.  The replay runs everything on the one stream, so it does
+     * not overlap a batch's RANSAC rounds with the next batch's detection: meant for
+     * small batches.  Same results.  0 (default): off.  Environment:
+     * VO_PIPELINE_GRAPH. */
+    VO_OPT_PIPELINE_GRAPH = 8,
+    VO_OPT_COUNT = 9
 };
 int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
 int vo_ctx_get_option(const vo_ctx* ctx, int option, int* value);

@@ -1007,6 +1007,80 @@ def test_pipeline_results_do_not_depend_on_matcher_variant(ctx):
 
 
 @pytest.mark.gpu
+def test_pipeline_graph_replay_equals_launches(ctx, options):
+    """VO_OPT_PIPELINE_GRAPH: a pipeline call that repeats the previous one's arguments is captured
+    as a HIP graph on its second occurrence and replayed from the third on.  Replays must give
+    the records of the ordinary launch chain, also after a different call in between (which
+    retires the graph), around an estimate_motion call on the shared workspace, with tickets that
+    can be waited for, and for the sequence form."""
+    import torch
+    from visual_odometry_amd import capi
+    frames_a, frames_b = [], []
+    for p in range(3):
+        frames_a += list(synth.frame_pair(900 + p))
+    for p in range(2):
+        frames_b += list(synth.frame_pair(950 + p))
+    imgs_a = torch.from_numpy(np.stack(frames_a)).cuda()
+    imgs_b = torch.from_numpy(np.stack(frames_b)).cuda()
+    res_a = torch.zeros(3 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    res_b = torch.zeros(2 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    res_s = torch.zeros(5 * capi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+
+    def run_a():
+        ctx.pipeline_pairs_dev(imgs_a.data_ptr(), 3, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res_a.data_ptr())
+
+    def run_b():
+        ctx.pipeline_pairs_dev(imgs_b.data_ptr(), 2, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                               res_b.data_ptr())
+
+    def run_s():   # six frames as a sequence: five pairs
+        ctx.pipeline_sequence_dev(imgs_a.data_ptr(), 6, 480, 640, 640, 480 * 640, 1500, 0.75, TUM_K, 1.0, 0.999, 0,
+                                  res_s.data_ptr())
+
+    def fetch(t):
+        ctx.sync()
+        return t.cpu().numpy().tobytes()
+
+    run_a(); want_a = fetch(res_a)
+    run_b(); want_b = fetch(res_b)
+    run_s(); want_s = fetch(res_s)
+    assert (np.frombuffer(want_a, capi.PAIR_DTYPE)["inliers"] > 50).all()
+    rng = np.random.default_rng(5)
+    p1 = rng.uniform(50, 590, (300, 2)).astype(np.float32)
+    p2 = p1 + rng.normal(0, 3, p1.shape).astype(np.float32)
+    ref_motion = ctx.estimate_motion(p1, p2, TUM_K)
+
+    options("pipeline_graph", 1)
+    for rep in range(5):          # ordinary, captured + replayed, replayed ...
+        res_a.zero_()
+        run_a()
+        assert fetch(res_a) == want_a, rep
+    res_b.zero_()
+    run_b()                       # another call: the graph is retired, this one runs the ordinary way
+    assert fetch(res_b) == want_b
+    for rep in range(3):          # a burst without a fence in between, then results by ticket
+        res_a.zero_()
+        torch.cuda.synchronize()
+        run_a()
+        run_a()
+        run_a()
+        ticket = ctx.pipeline_ticket()
+        ctx.pipeline_wait(ticket, results=True)
+        assert res_a.cpu().numpy().tobytes() == want_a
+        mid = ctx.estimate_motion(p1, p2, TUM_K)
+        assert mid["inliers"] == ref_motion["inliers"] and np.array_equal(mid["R"], ref_motion["R"])
+    for rep in range(4):
+        res_s.zero_()
+        run_s()
+        assert fetch(res_s) == want_s, rep
+    options("pipeline_graph", 0)
+    res_a.zero_()
+    run_a()
+    assert fetch(res_a) == want_a
+
+
+@pytest.mark.gpu
 def test_pipeline_back_to_back_calls_are_independent(ctx):
     """Calls only enqueue (the RANSAC rounds of one call overlap the detection of the next on a
     second stream): a burst of calls with different batches, one sync at the end, must give each

@@ -32,7 +32,7 @@ TRUNC_SCORE_LIST, TRUNC_KEYPOINT_LIST, TRUNC_OUTPUT = 1, 2, 4   # vo_pair_result
 WAIT_INPUTS, WAIT_RESULTS = 1, 2                                 # vo_pipeline_wait (VO_WAIT_*)
 # vo_ctx_set_option / vo_ctx_get_option (VO_OPT_*)
 OPTIONS = {"five_point_literal": 0, "fast_raise": 1, "knn_mode": 2, "knn_waves": 3, "knn_queries_per_lane": 4,
-           "second_chart": 5, "knn_train_split": 6, "solve_variant": 7}
+           "second_chart": 5, "knn_train_split": 6, "solve_variant": 7, "pipeline_graph": 8}
 T_GROUPS = ["resize", "fast", "select", "blur", "describe", "knn2", "ratio", "ransac",
             "ransac_solve", "ransac_score"]          # the last two split the RANSAC chain per round
 T_TOP = T_GROUPS[:8]

@@ -32,6 +32,7 @@ int ensure(vo_ctx* c, DevBuf& b, size_t bytes) {
         return fail(c, VO_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
     }
     b.bytes = want;
+    ++c->alloc_count;
     return VO_OK;
 }
 
@@ -129,6 +130,7 @@ static bool option_admits(int option, int v) {
         case VO_OPT_SECOND_CHART: return v == 0 || v == 1;
         case VO_OPT_KNN_TRAIN_SPLIT: return v >= 0 && v <= 64;
         case VO_OPT_SOLVE_VARIANT: return v == 0 || v == 1;
+        case VO_OPT_PIPELINE_GRAPH: return v == 0 || v == 1;
         default: return false;
     }
 }
@@ -138,7 +140,8 @@ static void option_defaults(vo_ctx* c) {
         {VO_OPT_FIVE_POINT_LITERAL, "VO_FIVE_POINT_LITERAL", 0}, {VO_OPT_FAST_RAISE, "VO_FAST_RAISE", -1},
         {VO_OPT_KNN_MODE, "VO_KNN_MODE", -1},                     {VO_OPT_KNN_WAVES, "VO_KNN_NW", 0},
         {VO_OPT_KNN_QUERIES_PER_LANE, "VO_KNN_QPL", 0},           {VO_OPT_SECOND_CHART, "VO_SECOND_CHART", 1},
-        {VO_OPT_KNN_TRAIN_SPLIT, "VO_KNN_SPLIT", 0},              {VO_OPT_SOLVE_VARIANT, "VO_SOLVE_VARIANT", 0}};
+        {VO_OPT_KNN_TRAIN_SPLIT, "VO_KNN_SPLIT", 0},              {VO_OPT_SOLVE_VARIANT, "VO_SOLVE_VARIANT", 0},
+        {VO_OPT_PIPELINE_GRAPH, "VO_PIPELINE_GRAPH", 0}};
     for (const auto& t : table) {
         int v = t.dflt;
         if (const char* e = getenv(t.env)) {
@@ -207,6 +210,8 @@ extern "C" int vo_ctx_create(int device, vo_ctx** out) {
 extern "C" void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->alt.side) (void)hipStreamSynchronize(c->alt.side);

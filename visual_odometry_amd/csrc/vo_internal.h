@@ -160,6 +160,24 @@ struct vo_ctx {
     vo::DevBuf r_state, r_samples, r_models, r_nmodels, r_models2, r_nmodels2, r_retry, r_roots, r_nroots, r_counts, r_best, r_mask, r_pts, r_ptsf, r_res;
     // pipeline workspace
     vo::DevBuf p_kps, p_desc, p_cnt;
+    // VO_OPT_PIPELINE_GRAPH: the launch chain of the most recent repeated pipeline call as a HIP
+    // graph.  graph_key: the call it was captured from (arguments, options, allocation count);
+    // graph_seen: the last call that ran the ordinary way (a call is captured when it comes twice
+    // in a row); alloc_count: workspace (re)allocations so far - a graph holds device addresses,
+    // so any of them retires it.
+    struct PipelineKey {
+        const void* imgs;
+        void* results;
+        size_t image_stride;
+        double K[4], threshold, confidence;
+        float ratio;
+        int n_images, n_pairs, pair_step, rows, cols, step, max_features, fixed_iters;
+        int opt[VO_OPT_COUNT];
+        unsigned long long alloc_count;
+    };
+    PipelineKey graph_key{}, graph_seen{};
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned long long alloc_count = 0;
 };
 
 namespace vo {

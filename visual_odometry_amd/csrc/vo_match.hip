@@ -609,12 +609,15 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
                 int nq_typical) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
     if (int jrc = join_tail(c)) return jrc;   // the table below may still be read by the previous batch's ratio test
-    // Queries per lane.  One query per lane measures fastest on everything up to
+    // The kernel: the matrix-core one unless VO_OPT_KNN_MODE says otherwise (0: the scalar-operand
+    // vector kernel, 1: the vector kernel with the train rows broadcast from LDS; tuning and test aids).
+    const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 2 : c->opt[VO_OPT_KNN_MODE];
+    // Queries per lane of the vector kernels.  One query per lane measures fastest on everything up to
     // 65 536 x 65 536 (a train set of 2 MB stays in the L2 caches, whatever the batch); more
     // queries per lane only pay once the train set is larger and the grid so large that its
     // re-reads (one pass per workgroup) start to matter.
     int qpl = 1;
-    if (nt_max > 65536) {
+    if (nt_max > 65536 && mode < 2) {
         qpl = 4;
         while (qpl > 1 && (long long)((nq_max + 64 * qpl - 1) / (64 * qpl)) * batch < 16384) qpl >>= 1;
     }
@@ -622,9 +625,6 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
     hipStream_t s = c->stream;
     t_begin(c, VO_T_KNN2);
-    // One query per lane: the variant with the train rows in vector registers.  VO_OPT_KNN_MODE = 0
-    // selects the scalar-operand kernel instead (tuning aid).
-    const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 2 : c->opt[VO_OPT_KNN_MODE];
     if (qpl == 1 && mode >= 1) {
         // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
         // still has several to switch between.  Many (a batch of some hundred pairs): one

@@ -41,10 +41,110 @@ static int pipeline_body(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_p
                          int step, size_t image_stride, int max_features, float ratio, const double K[4],
                          double threshold, double confidence, int fixed_iters, vo_pair_result* d_results);
 
+// ---- VO_OPT_PIPELINE_GRAPH: a repeated call as one graph launch
+static void drop_graph(vo_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+}
+
+// Captures the call's launch chain on the main stream.  A capture cannot wait for events of work
+// outside it and records no event that anything outside could wait for, so: everything earlier is
+// waited for on the host first, the side and auxiliary streams are the main stream for the
+// duration (their fork / join events then order a stream behind itself), and the events the chain
+// touched are recorded again, outside the capture, before anyone looks at them.
+static int capture_graph(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
+                         int step, size_t image_stride, int max_features, float ratio, const double K[4],
+                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
+    drop_graph(c);
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->side));
+    VO_HIP(c, hipStreamSynchronize(c->alt.side));
+    VO_HIP(c, hipStreamSynchronize(c->aux));
+    c->side_busy = c->alt.side_busy = false;
+    c->tail_pending = c->alt.tail_pending = false;
+    const hipStream_t side = c->side, aux = c->aux;
+    const unsigned long long seq = c->call_seq, allocs = c->alloc_count;
+    c->side = c->aux = c->stream;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    int rc = VO_OK;
+    if (e == hipSuccess) {
+        rc = pipeline_body(c, d_imgs, n_images, n_pairs, pair_step, rows, cols, step, image_stride, max_features, ratio, K,
+                           threshold, confidence, fixed_iters, d_results);
+        e = hipStreamEndCapture(c->stream, &graph);
+    }
+    c->side = side;
+    c->aux = aux;
+    c->call_seq = seq;   // (the replay takes the ticket)
+    c->side_busy = c->tail_pending = false;
+    if (rc == VO_OK && e == hipSuccess && c->alloc_count != allocs) {
+        rc = fail(c, VO_ERR_HIP, "pipeline graph: the captured call allocated workspace");
+    }
+    if (rc == VO_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    // the events the chain recorded inside the capture, made ordinary events again
+    hipEvent_t touched[] = {c->ev_init, c->ev_rdone, c->ev_tail, c->ev_fork, c->ev_fast0, c->ev_blur,
+                            c->ev_in[(seq + 1) % VO_TICKET_RING], c->ev_out[(seq + 1) % VO_TICKET_RING]};
+    for (hipEvent_t ev : touched)
+        if (ev) (void)hipEventRecord(ev, c->stream);
+    if (rc != VO_OK) {
+        drop_graph(c);
+        return rc;
+    }
+    if (e != hipSuccess) {
+        drop_graph(c);
+        (void)hipGetLastError();
+        return fail(c, VO_ERR_HIP, std::string("pipeline graph capture: ") + hipGetErrorString(e));
+    }
+    return VO_OK;
+}
+
 static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pairs, int pair_step, int rows, int cols,
                         int step, size_t image_stride, int max_features, float ratio, const double K[4],
                         double threshold, double confidence, int fixed_iters, vo_pair_result* d_results) {
     VO_HIP(c, hipSetDevice(c->device));
+    auto make_key = [&]() {
+        vo_ctx::PipelineKey k;
+        memset(&k, 0, sizeof(k));   // (the key is compared byte by byte, padding included)
+        k.imgs = d_imgs;
+        k.results = d_results;
+        k.image_stride = image_stride;
+        for (int i = 0; i < 4; ++i) k.K[i] = K[i];
+        k.threshold = threshold;
+        k.confidence = confidence;
+        k.ratio = ratio;
+        k.n_images = n_images; k.n_pairs = n_pairs; k.pair_step = pair_step; k.rows = rows; k.cols = cols; k.step = step;
+        k.max_features = max_features; k.fixed_iters = fixed_iters;
+        for (int i = 0; i < VO_OPT_COUNT; ++i) k.opt[i] = c->opt[i];
+        k.alloc_count = c->alloc_count;
+        return k;
+    };
+    if (c->opt[VO_OPT_PIPELINE_GRAPH] == 1 && !c->timing && !c->fast_stats_on) {
+        const vo_ctx::PipelineKey k = make_key();
+        if (!c->graph_exec || memcmp(&k, &c->graph_key, sizeof(k)) != 0) {
+            if (memcmp(&k, &c->graph_seen, sizeof(k)) == 0) {   // the second call in a row with these arguments
+                const int crc = capture_graph(c, d_imgs, n_images, n_pairs, pair_step, rows, cols, step, image_stride,
+                                              max_features, ratio, K, threshold, confidence, fixed_iters, d_results);
+                if (crc != VO_OK) return crc;
+                c->graph_key = k;
+            } else {
+                drop_graph(c);
+            }
+        }
+        if (c->graph_exec) {
+            // the replay runs on the main stream, behind whatever earlier calls left on the others
+            if (int jrc = join_side(c)) return jrc;
+            if (int jrc = join_tail(c)) return jrc;
+            VO_HIP(c, hipGraphLaunch(c->graph_exec, c->stream));
+            const unsigned long long ticket = c->call_seq + 1;
+            VO_HIP(c, hipEventRecord(c->ev_in[ticket % VO_TICKET_RING], c->stream));
+            VO_HIP(c, hipEventRecord(c->ev_out[ticket % VO_TICKET_RING], c->stream));
+            c->call_seq = ticket;
+            return VO_OK;
+        }
+    } else if (c->graph_exec) {
+        drop_graph(c);
+    }
     // this call's tail takes the tail set the call before the previous one used: it runs beside
     // the previous call's tail (and behind the older one, in stream order).  A call that fails
     // takes no ticket, so it gives the set back: tickets and tail sets stay in step (a ticket's
@@ -53,6 +153,9 @@ static int pipeline_run(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_pa
     const int rc = pipeline_body(c, d_imgs, n_images, n_pairs, pair_step, rows, cols, step, image_stride, max_features,
                                  ratio, K, threshold, confidence, fixed_iters, d_results);
     if (rc != VO_OK) c->swap_tail();
+    if (rc == VO_OK && c->opt[VO_OPT_PIPELINE_GRAPH] == 1) {
+        c->graph_seen = make_key();   // (after the call: what it allocated is there now)
+    }
     return rc;
 }
 
