@@ -514,6 +514,25 @@ def main():
     line["pair_roofline"] = pair_roofline(H, W, work, P, dt / args.steps)
 
     if not args.no_extras:
+        # The headline workload with the matcher on the vector ALUs only (VO_OPT_KNN_MODE = 1, the
+        # xor / popcount kernel): what the step costs without matrix instructions.
+        for c in ctxs:
+            c.set_option("knn_mode", 1)
+        for _ in range(2):
+            run.step()
+        run.fence()
+        v_steps = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(v_steps):
+            run.step()
+        run.fence()
+        v_dt = rank_max(torch, dist, time.perf_counter() - t0)
+        for c in ctxs:
+            c.set_option("knn_mode", -1)
+        line["vector_alu_matcher"] = {"value": P * v_steps * world / v_dt, "unit": "frame-pairs/s",
+                                      "ms_per_step": 1e3 * v_dt / v_steps, "steps": v_steps,
+                                      "note": "same workload, Hamming distances by xor + popcount on the vector ALUs "
+                                              "instead of fp4 matrix instructions; identical results"}
         # Synchronous steps (a fence after each): the distribution of one batch's latency.  Larger
         # than ms_per_step, where a batch's RANSAC tail runs beside the next batch's detection.
         lat = []
@@ -778,6 +797,18 @@ def main():
             ctx.sync()
             shard_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
             ctx.set_timing(False)
+        # the same search by the vector-ALU kernel (xor + popcount on 32-byte rows, no matrix
+        # instructions: VO_OPT_KNN_MODE = 1), for comparison
+        valu_ms = None
+        if world == 1:
+            ctx.set_option("knn_mode", 1)
+            ctx.set_timing(True, groups=["knn2"])
+            for _ in range(3):
+                ctx.hamming_knn2_dev(q_all.data_ptr(), nq_total, tr.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+            ctx.sync()
+            valu_ms = ctx.kernel_time_ms(capi.T_GROUPS.index("knn2"))[0]
+            ctx.set_timing(False)
+            ctx.set_option("knn_mode", -1)
         alg_bytes = float(nq_total) * nt * 32
         flops = KNN_FLOPS * nq_total * nt
         line["hamming"] = {"workload": "c4_hamming_65536x65536", "value": alg_bytes / hd / 1e9,
@@ -797,6 +828,13 @@ def main():
                                                 "instructions: two operations per distance keep the two best, seven "
                                                 "per train dword turn bits into fp4 signs, and each matrix "
                                                 "instruction holds the issue port for about 18 cycles"},
+                           "vector_alu_kernel": None if valu_ms is None else {
+                               "kernel": "knn2_bcast_kernel", "ms": valu_ms, "value": alg_bytes / (valu_ms * 1e-3) / 1e9,
+                               "unit": "GB/s (Nq*Nt*32 B / s)",
+                               "frac_of_int_lane_peak": 20.0 * nq_total * nt / (valu_ms * 1e-3) / 78.6e12,
+                               "note": "VO_OPT_KNN_MODE = 1: 8 xor + 8 v_bcnt + top-2 per query x train row, 20 "
+                                       "lane-operations against 256 CUs x 4 SIMDs x 32 lanes per clock; its "
+                                       "half-rate instructions cap the mix near 0.55"},
                            "compulsory_hbm_bytes": (nq_total + nt) * 32 + nq_total * 16}
         del q_all, tr
 
