@@ -140,7 +140,9 @@ enum {
     /* Hamming search kernel: -1 (default) and 2 the matrix-core kernel, 0 the
      * scalar-operand vector kernel, 1 the LDS-broadcast vector kernel (which
      * hands train sets beyond 65 536 rows with very large grids to the
-     * scalar-operand one).  All give the same table.  Environment: VO_KNN_MODE. */
+     * scalar-operand one), 3 the matrix-core kernel with four query groups per
+     * wavefront whatever the size (test aid).  All give the same table.
+     * Environment: VO_KNN_MODE. */
     VO_OPT_KNN_MODE = 2,
     /* Wavefronts per workgroup of the matrix-core and LDS-broadcast kernels: 0
      * (default) by size, else 1, 4, 8 or 16.  Environment: VO_KNN_NW. */

@@ -38,7 +38,8 @@ def test_knn2_matches_oracle(ctx, oracle, nq, nt):
                                   "knn_mode=1,knn_waves=1", "knn_mode=1,knn_waves=4", "knn_mode=1,knn_waves=8",
                                   "knn_mode=1,knn_waves=16", "knn_queries_per_lane=2", "knn_queries_per_lane=4",
                                   "knn_train_split=2", "knn_train_split=5", "knn_train_split=64",
-                                  "knn_mode=1,knn_train_split=5"])
+                                  "knn_mode=1,knn_train_split=5", "knn_mode=3", "knn_mode=3,knn_waves=1",
+                                  "knn_mode=3,knn_waves=4", "knn_mode=3,knn_waves=8", "knn_mode=3,knn_train_split=5"])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (70, 3), (300, 257), (2000, 2000), (31, 4097), (1500, 70000)])
 def test_knn2_every_launch_variant(ctx, oracle, options, knob, nq, nt):
     """The matcher picks its kernel and workgroup size from the problem size (the matrix-core kernel
@@ -997,7 +998,7 @@ def test_pipeline_results_do_not_depend_on_matcher_variant(ctx):
 
     want = run()
     assert np.frombuffer(want, capi.PAIR_DTYPE)["n_matches"].min() > 50
-    for knob in ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_mode=0", "knn_mode=1", "knn_queries_per_lane=2",
+    for knob in ["knn_waves=1", "knn_waves=4", "knn_waves=8", "knn_mode=0", "knn_mode=1", "knn_mode=3", "knn_queries_per_lane=2",
                  "knn_queries_per_lane=4"]:
         name, value = knob.split("=")
         before = ctx.get_option(name)

@@ -124,7 +124,7 @@ static bool option_admits(int option, int v) {
     switch (option) {
         case VO_OPT_FIVE_POINT_LITERAL: return v == 0 || v == 1;
         case VO_OPT_FAST_RAISE: return v >= -1 && v <= 1;
-        case VO_OPT_KNN_MODE: return v >= -1 && v <= 2;
+        case VO_OPT_KNN_MODE: return v >= -1 && v <= 3;
         case VO_OPT_KNN_WAVES: return v == 0 || v == 1 || v == 4 || v == 8 || v == 16;
         case VO_OPT_KNN_QUERIES_PER_LANE: return v == 0 || v == 1 || v == 2 || v == 4;
         case VO_OPT_SECOND_CHART: return v == 0 || v == 1;

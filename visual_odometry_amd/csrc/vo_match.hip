@@ -367,22 +367,25 @@ __device__ __forceinline__ float min2f(float a, float b) {
     return __builtin_bit_cast(float, min(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)));
 }
 
-template <int NW>   // wavefronts per workgroup: they split the train rows and merge at the end
-__global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr,
+// NW: wavefronts per workgroup (they split the train rows and merge at the end); G: groups of 32
+// queries per wavefront (the expansion of a train tile is shared by a wavefront's groups)
+template <int NW, int G>
+__global__ __launch_bounds__(64 * NW, G <= 2 && NW <= 8 ? 4 : 2) void knn2_mfma_kernel(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr,
                                                         int cnt_stride, int nq_max, size_t q_stride,
                                                         const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr,
                                                         int nt_max, size_t t_stride, int32_t* __restrict__ idx2,
                                                         int32_t* __restrict__ dist2, int rows_per_z,
                                                         unsigned long long* __restrict__ part_out) {
-    __shared__ unsigned long long part[NW][64][2];
-    __shared__ unsigned long long lane_best[64 * NW][2][2];   // [lane][query group][first, second]
+    constexpr int QW = 32 * G;   // queries per wavefront and workgroup
+    __shared__ unsigned long long part[NW][QW][2];
+    __shared__ unsigned long long lane_best[64 * NW][G][2];   // [lane][query group][first, second]
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the loop's row counters follow from it)
     const int col = lane & 31, half = lane >> 5;
     const int nq = nq_arr ? min(nq_arr[b * cnt_stride], nq_max) : nq_max;
     const int nt = nt_arr ? min(nt_arr[b * cnt_stride], nt_max) : nt_max;
-    const int qbase = blockIdx.x * 64;
+    const int qbase = blockIdx.x * QW;
     if (qbase >= nq) return;
     const uint8_t* qb = q + (size_t)b * q_stride;
     const uint8_t* tb = t + (size_t)b * t_stride;
@@ -391,9 +394,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
     // the negative product)
     uint32_t sign_mask = 0x88888888u, mag_q = 0x66666666u, mag_t = 0x44444444u;
     asm volatile("" : "+s"(sign_mask), "+v"(mag_q), "+v"(mag_t));   // (no instruction: keeps them out of constant folding)
-    v8i32 Bq[2][4];
+    v8i32 Bq[G][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         const int qi = min(qbase + 32 * g + col, nq - 1);
         const uint4 raw = *reinterpret_cast<const uint4*>(qb + (size_t)qi * 32 + 16 * half);
         Bq[g][0] = fp4_signs(~raw.x, sign_mask, mag_q);
@@ -408,22 +411,25 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
 
     // (the two best over the chunks done so far wait in LDS, not in eight registers of the loop)
     unsigned long long (*best)[2] = lane_best[tid];
-    best[0][0] = best[0][1] = best[1][0] = best[1][1] = ~0ull;
+#pragma unroll
+    for (int g = 0; g < G; ++g) best[g][0] = best[g][1] = ~0ull;
     const int t_lo = min((int)blockIdx.z * (long long)rows_per_z, (long long)nt);
     const int t_hi = (int)min((long long)nt, (long long)t_lo + rows_per_z);
 
     for (int cbase = t_lo; cbase < t_hi; cbase += MF_CHUNK) {
         const int cn = min(t_hi - cbase, MF_CHUNK);
-        float k0[2] = {MF_NONE, MF_NONE}, k1[2] = {MF_NONE, MF_NONE};
+        float k0[G], k1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) k0[g] = k1[g] = MF_NONE;
         const uint8_t* tcb = tb + (size_t)cbase * 32;
         auto fetch = [&](int first) {   // row first + col (clamped), this lane's half of it
             return *reinterpret_cast<const uint4*>(tcb + (size_t)min(first + col, cn - 1) * 32 + 16 * half);
         };
-        auto tile = [&](const uint4& raw, int rows_left, bool late) {   // one 32-row tile against both query groups
+        auto tile = [&](const uint4& raw, int rows_left, bool late) {   // one 32-row tile against the query groups
             const v8i32 A0 = fp4_signs(raw.x, sign_mask, mag_t), A1 = fp4_signs(raw.y, sign_mask, mag_t);
             const v8i32 A2 = fp4_signs(raw.z, sign_mask, mag_t), A3 = fp4_signs(raw.w, sign_mask, mag_t);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 v16f32 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, Bq[g][0], c_in, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, Bq[g][1], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A2, Bq[g][2], acc, 4, 4, 0, MF_SCALE_ONE, 0, MF_SCALE_2K);
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         };
         auto age = [&](float rows) {   // the frame moves on by `rows`: rows seen so far fall behind
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 k0[g] -= rows;
                 k1[g] -= rows;
             }
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         }
         // keys -> (distance << 32 | row); the two halves of the wavefront saw different rows
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
             unsigned long long e[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         }
     }
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         unsigned long long b0 = best[g][0], b1 = best[g][1];
         const unsigned long long o0 = __shfl_xor(b0, 32), o1 = __shfl_xor(b1, 32);
         merge2(b0, b1, o0, o1);
@@ -501,17 +507,17 @@ __global__ __launch_bounds__(64 * NW, NW <= 8 ? 4 : 2) void knn2_mfma_kernel(con
         }
     }
     __syncthreads();
-    if (tid < 64) {
-        const int qi = qbase + tid;
+    for (int qo = tid; qo < QW; qo += 64 * NW) {
+        const int qi = qbase + qo;
         if (qi < nq) {
-            unsigned long long a0 = part[0][tid][0], a1 = part[0][tid][1];
+            unsigned long long a0 = part[0][qo][0], a1 = part[0][qo][1];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) merge2(a0, a1, part[w][tid][0], part[w][tid][1]);
+            for (int w = 1; w < NW; ++w) merge2(a0, a1, part[w][qo][0], part[w][qo][1]);
             if (part_out) {   // split search: the chunk's two best as keys, merged by knn2_merge_kernel
                 const size_t po = (((size_t)b * gridDim.z + blockIdx.z) * nq_max + qi) * 2;
                 part_out[po] = a0;
                 part_out[po + 1] = a1;
-                return;
+                continue;
             }
             const size_t o = ((size_t)b * nq_max + qi) * 2;
             idx2[o] = a0 == ~0ull ? -1 : (int32_t)(uint32_t)a0;
@@ -632,9 +638,16 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
         // two best about a third as often as four wavefronts with a quarter of the rows each
         // (2 ln n events per query against 4 x 2 ln(n/4)), and nothing is left to merge; 7 % less
         // kernel time at 512 pairs, but only with 12 or more wavefronts per SIMD to draw from.
-        const long long wgs = (long long)grid.x * grid.y;
         const int nq_live = nq_typical > 0 ? std::min(nq_typical, nq_max) : nq_max;
-        const long long live = (long long)((nq_live + 63) / 64) * batch;
+        // The matrix-core kernel with four groups of 32 queries per wavefront instead of two (the
+        // expansion of a train tile into fp4 signs is shared by a wavefront's groups): pays on long
+        // scans (65 536 x 65 536: -13 %), loses on the pipeline's per-pair searches (2 000 x 2 000 in
+        // batches of 512: 0.53 against 0.33 ms - a third fewer wavefronts per SIMD, 128-query blocks
+        // that the last wavefront of a pair fills badly).  Mode 3 forces it (test aid).
+        const int groups = mode >= 3 || (mode == 2 && !d_nt && nt_max >= 16384 && nq_max >= 4096) ? 4 : 2;
+        if (mode >= 2) grid.x = (nq_max + 32 * groups - 1) / (32 * groups);
+        const long long wgs = (long long)grid.x * grid.y;
+        const long long live = (long long)((nq_live + 32 * groups - 1) / (32 * groups)) * batch * (groups / 2);
         int nw = live >= 12 * 1024 ? 1 : wgs * 4 >= 8 * 1024 ? 4 : wgs * 8 >= 8 * 1024 ? 8 : 16;
         // Fewer than four workgroups per compute unit even so (a shard of a large match): the train
         // set is split as well, into chunks of whole 64-row blocks with at least 128 rows for each
@@ -643,10 +656,11 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
         // (only where the train count is known on the host and large: the pipeline's per-pair
         // searches pass capacities and are batched instead)
         if (wgs < 1024 && !d_nt && nt_max >= 8192) {
-            nw = 8;
+            nw = groups == 4 ? 4 : 8;
             split = (int)std::min<long long>({64, (1024 + wgs - 1) / wgs, nt_max / 1024});
         }
         if (c->opt[VO_OPT_KNN_WAVES] > 0) nw = c->opt[VO_OPT_KNN_WAVES];   // tuning aids
+        if (groups == 4 && nw > 8) nw = 8;
         if (c->opt[VO_OPT_KNN_TRAIN_SPLIT] > 0) split = c->opt[VO_OPT_KNN_TRAIN_SPLIT];
         split = std::max(1, std::min(split, (nt_max + 63) / 64));
         int rows_per_z = 0x7FFFFFFF;
@@ -664,12 +678,24 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     hipLaunchKernelGGL(KERNEL<NW>, grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max, \
                        t_stride, d_idx2, d_dist2, rows_per_z, part)
         if (mode >= 2) {   // the matrix-core kernel
-            switch (nw) {
-                case 1: VO_KNN_LAUNCH(knn2_mfma_kernel, 1); break;
-                case 4: VO_KNN_LAUNCH(knn2_mfma_kernel, 4); break;
-                case 8: VO_KNN_LAUNCH(knn2_mfma_kernel, 8); break;
-                default: VO_KNN_LAUNCH(knn2_mfma_kernel, 16); break;
+#define VO_MFMA_LAUNCH(NW, G)                                                                                            \
+    hipLaunchKernelGGL((knn2_mfma_kernel<NW, G>), grid, dim3(64 * NW), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, \
+                       d_nt, nt_max, t_stride, d_idx2, d_dist2, rows_per_z, part)
+            if (groups == 4) {
+                switch (nw) {
+                    case 1: VO_MFMA_LAUNCH(1, 4); break;
+                    case 4: VO_MFMA_LAUNCH(4, 4); break;
+                    default: VO_MFMA_LAUNCH(8, 4); break;
+                }
+            } else {
+                switch (nw) {
+                    case 1: VO_MFMA_LAUNCH(1, 2); break;
+                    case 4: VO_MFMA_LAUNCH(4, 2); break;
+                    case 8: VO_MFMA_LAUNCH(8, 2); break;
+                    default: VO_MFMA_LAUNCH(16, 2); break;
+                }
             }
+#undef VO_MFMA_LAUNCH
         } else {
             switch (nw) {
                 case 1: VO_KNN_LAUNCH(knn2_bcast_kernel, 1); break;
@@ -766,7 +792,7 @@ extern "C" int vo_match_ratio_static(vo_ctx* c, const uint8_t* d_q, int nq, cons
         // the matrix-core kernel; four wavefronts per workgroup suit every size this entry point
         // admits
         dim3 grid((nq + 63) / 64, 1);
-        hipLaunchKernelGGL(knn2_mfma_kernel<4>, grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
+        hipLaunchKernelGGL((knn2_mfma_kernel<4, 2>), grid, dim3(256), 0, s, d_q, (const int32_t*)nullptr, 1, nq, (size_t)0, d_t,
                            (const int32_t*)nullptr, nt, (size_t)0, idx2, dist2, 0x7FFFFFFF, (unsigned long long*)nullptr);
     }
     hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)idx2, (const int32_t*)dist2,
