@@ -175,6 +175,7 @@ struct vo_ctx {
         int opt[VO_OPT_COUNT];
         unsigned long long alloc_count;
     };
+    bool ransac_short_hint = false;   // the last RANSAC call from host points ended within its first round
     PipelineKey graph_key{}, graph_seen{};
     hipGraphExec_t graph_exec = nullptr;
     unsigned long long alloc_count = 0;
@@ -225,6 +226,6 @@ int static_scratch_init(vo_ctx* c);
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
                double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
-               int samples_cap, bool on_side);
+               int samples_cap, bool on_side, bool ask_after_first_round = false);
 
 }  // namespace vo

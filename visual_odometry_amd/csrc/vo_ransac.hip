@@ -2414,7 +2414,7 @@ static int round_size(int round, int batch) {
 int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d_n, int n_max, int batch,
                const double K[4], double threshold, double confidence, int fixed_iters, vo_pair_result* d_res,
                double* d_E, uint8_t* d_mask_e, uint8_t* d_mask_pose, int32_t* d_good, int32_t* d_samples,
-               int samples_cap, bool on_side) {
+               int samples_cap, bool on_side, bool ask_after_first_round) {
     if (batch <= 0) return VO_OK;
     // on_side: the caller (the batched pipeline) has already ordered the side stream behind the
     // matches; everything below is enqueued there, one batch after the other, so the workspace
@@ -2586,6 +2586,15 @@ int ransac_dev(vo_ctx* c, const float* d_p1, const float* d_p2, const int32_t* d
             update(h0, hr, hr, 0, std::min(next, kChunk), 0, next <= 0);
         }
         h0 += hr;
+        // A caller that waits for the result anyway (one pair from host points) and whose last call
+        // ended within the first round asks here whether this one has, too: a 4-byte read-back
+        // against the sixteen launches of two rounds that would find the pair finished.
+        if (round == 0 && ask_after_first_round && batch == 1 && fixed_iters <= 0) {
+            int done = 0;
+            VO_HIP(c, hipMemcpyAsync(&done, (const char*)st + offsetof(RState, done), sizeof(int), hipMemcpyDeviceToHost, s));
+            VO_HIP(c, hipStreamSynchronize(s));
+            if (done) break;
+        }
     }
     hipLaunchKernelGGL(finish_kernel, dim3(batch), dim3(4 * FIN_T), 0, s, st, m, nm, P, d_res, d_E, d_mask_e, d_mask_pose,
                        d_good);
@@ -2629,7 +2638,7 @@ static int run_host_ransac(vo_ctx* c, const float* p1, const float* p2, int n, c
     }
     if (d_samples) VO_HIP(c, hipMemsetAsync(d_samples, 0xFF, log_bytes, c->stream));
     if ((rc = ransac_dev(c, (const float*)c->m_p1.p, (const float*)c->m_p2.p, nullptr, n, 1, K, threshold, confidence,
-                         fixed_iters, d_res, d_E, d_me, d_mp, d_good, d_samples, samples_cap, false)))
+                         fixed_iters, d_res, d_E, d_me, d_mp, d_good, d_samples, samples_cap, false, c->ransac_short_hint)))
         return rc;
     VO_HIP(c, hipMemcpyAsync(res, d_res, sizeof(vo_pair_result), hipMemcpyDeviceToHost, c->stream));
     if (E) VO_HIP(c, hipMemcpyAsync(E, d_E, 72, hipMemcpyDeviceToHost, c->stream));
@@ -2638,6 +2647,8 @@ static int run_host_ransac(vo_ctx* c, const float* p1, const float* p2, int n, c
     if (mask_pose && n > 0) VO_HIP(c, hipMemcpyAsync(mask_pose, d_mp, n, hipMemcpyDeviceToHost, c->stream));
     if (samples) VO_HIP(c, hipMemcpyAsync(samples, d_samples, log_bytes, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    // (what the next call from host points goes by: whether this one ended within the first round)
+    c->ransac_short_hint = fixed_iters <= 0 && res->ransac_iters > 0 && res->ransac_iters <= round_size(0, 1);
     return VO_OK;
 }
 
