@@ -1008,6 +1008,39 @@ def test_pipeline_results_do_not_depend_on_matcher_variant(ctx):
 
 
 @pytest.mark.gpu
+def test_estimate_motion_repeated_calls_agree(ctx, oracle):
+    """A call from host points whose predecessor ended within the first RANSAC round asks the GPU
+    after its own first round whether it may stop launching: the same points must give the same
+    answer whether the call came first (no such question), second or third, and whether the call
+    before it was an easy or a hard one."""
+    rng = np.random.default_rng(77)
+    easy1 = rng.uniform(40, 600, (400, 2)).astype(np.float32)
+    R = np.array([[0.9998, -0.01, 0.017], [0.01, 0.99995, 0.0], [-0.017, 0.0, 0.99985]])
+    depth = rng.uniform(2, 6, 400)
+    Kf = np.array([[TUM_K[0], 0, TUM_K[2]], [0, TUM_K[1], TUM_K[3]], [0, 0, 1]])
+    X = (np.linalg.inv(Kf) @ np.c_[easy1, np.ones(400)].T) * depth
+    x2 = Kf @ (R @ X + np.array([[0.1], [0.02], [0.01]]))
+    easy2 = (x2[:2] / x2[2]).T.astype(np.float32)
+    hard1 = easy1.copy()
+    hard2 = easy2.copy()
+    hard2[:300] = rng.uniform(40, 600, (300, 2)).astype(np.float32)   # a quarter inliers: hundreds of hypotheses
+
+    def same(a, b):
+        return a["valid"] == b["valid"] and a["inliers"] == b["inliers"] and np.array_equal(a["R"], b["R"]) and \
+            np.array_equal(a["t"], b["t"]) and np.array_equal(a["mask"], b["mask"])
+
+    ref_easy = ctx.estimate_motion(easy1, easy2, TUM_K)
+    ref_hard = ctx.estimate_motion(hard1, hard2, TUM_K)
+    assert ref_easy["valid"] and ref_easy["inliers"] > 300
+    want = oracle.estimate_motion(easy1, easy2, TUM_K)
+    assert want["inliers"] == ref_easy["inliers"]
+    for seq in ("eee", "ehe", "hee", "ehhe"):
+        for kind in seq:
+            got = ctx.estimate_motion(easy1, easy2, TUM_K) if kind == "e" else ctx.estimate_motion(hard1, hard2, TUM_K)
+            assert same(got, ref_easy if kind == "e" else ref_hard), (seq, kind)
+
+
+@pytest.mark.gpu
 def test_pipeline_graph_replay_equals_launches(ctx, options):
     """VO_OPT_PIPELINE_GRAPH: a pipeline call that repeats the previous one's arguments is captured
     as a HIP graph on its second occurrence and replayed from the third on.  Replays must give
