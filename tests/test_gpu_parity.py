@@ -62,6 +62,34 @@ def test_knn2_every_launch_variant(ctx, oracle, options, knob, nq, nt):
     assert np.array_equal(gd, od)
 
 
+def test_knn2_random_shapes(ctx, oracle, options):
+    """Forty searches of random small shapes (1 .. 400 query rows, 1 .. 6000 train rows, with exact
+    copies and near copies planted) through the default kernel and through the matrix-core
+    kernel's other forms: tables bit-identical to the oracle's, row for row."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        nq = int(rng.integers(1, 401))
+        nt = int(rng.integers(1, 6001)) if case % 4 else int(rng.integers(1, 40))
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        for k in range(0, nq, 5):            # copies of train rows, some with one or two bits flipped
+            q[k] = t[rng.integers(0, nt)]
+            if k % 10 == 0:
+                q[k, rng.integers(0, 32)] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if nt > 3:
+            t[nt - 1] = t[0]                 # a tie between the first and the last train row
+            t[nt // 2] = t[0]
+        oi, od = oracle.knn2(q, t)
+        for knob in ("knn_mode=-1", "knn_mode=3", "knn_mode=2,knn_waves=1", "knn_mode=3,knn_waves=8,knn_train_split=3"):
+            for part in knob.split(","):
+                name, value = part.split("=")
+                options(name, int(value))
+            gi, gd = ctx.hamming_knn2(q, t)
+            assert np.array_equal(gi, oi) and np.array_equal(gd, od), (case, nq, nt, knob)
+            for part in knob.split(","):
+                options(part.split("=")[0], -1 if part.startswith("knn_mode") else 0)
+
+
 def test_knn2_empty_train(ctx):
     q = synth.descriptors(1, 10)
     gi, gd = ctx.hamming_knn2(q, np.zeros((0, 32), np.uint8))
