@@ -345,6 +345,27 @@ def _strong_texture_on_sampled_tiles(seed, height=480, width=640):
     return img
 
 
+def test_orb_detect_when_the_pretest_queue_overflows(ctx, oracle):
+    """FAST's first queue holds what half a tile can pass at most; a tile that passes more is worked
+    through in two halves of its rows.  A diagonal sawtooth makes nearly every pixel pass the
+    cardinal pre-test in both polarities (brighter to the north and east, darker to the south and
+    west), which overflows the queue in every tile; noise on top of it leaves real corners.  The
+    keypoints and descriptors must still be the oracle's, byte for byte."""
+    rng = np.random.default_rng(31)
+    yy, xx = np.mgrid[0:480, 0:640]
+    saw = ((9 * (xx - yy)) % 256).astype(np.int32)
+    for k, noise in enumerate((0, 12, 40)):
+        img = np.clip(saw + rng.integers(-noise, noise + 1, saw.shape), 0, 255).astype(np.uint8)
+        img[100:140, 200:260] = 0          # flat patches with sharp borders: some certain corners
+        img[300:330, 400:470] = 255
+        gk, gd = ctx.orb_detect(img, 1500)
+        ok, od = oracle.orb_detect(img, 1500)
+        assert len(gk) == len(ok) and len(gk) > 100, (k, len(gk), len(ok))
+        assert gk.tobytes() == ok.tobytes(), k
+        assert np.array_equal(gd, od), k
+
+
+
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 300), ("checker", 2000), ("kitti", 4000),
                                         ("odd", 500), ("narrow", 300), ("threshold", 800), ("sampled_strong", 2000),
                                         ("sampled_strong", 500)])

@@ -191,7 +191,12 @@ constexpr int FP_N = FP_H * FP_W;            // bytes of the pixel tile
 // queue group's darker-ring entries (which read the copy) and the brighter-ring entries of the
 // pixels next to them do not meet on one bank.
 constexpr int FI_OFF = FP_N + 64;
-constexpr int FQ1_N = 2 * FQ_N;              // a position can enter the first queue once per polarity
+// Capacity of the first queue.  A position can enter it once per polarity, 2 * FQ_N entries for the
+// whole tile, but hardly any tile needs half of that, and the full size costs the eighth
+// workgroup per compute unit (22.8 against 18.4 KB of LDS; the kernel is bound by the tiles it has
+// in flight).  It holds what half a tile can produce at most; a tile whose pre-test passes more
+// (pixel, polarity) pairs than fit is worked through in two halves of its rows.
+constexpr int FQ1_N = 2 * ((FS_H + 1) / 2) * (FT_W + 2) + 60;
 enum { FAST_PLAIN = 0, FAST_RAISED = 1, FAST_REDO = 2 };   // fast_kernel's mode
 
 // Largest minimum over the sixteen 9-arcs of the ring (Bresenham circle of radius 3) around
@@ -375,6 +380,15 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     }
     __syncthreads();
 
+    // Stages 1 and 2 run over score rows [row_lo, row_hi): the whole tile, unless its pre-test
+    // passes more entries than the first queue holds - then the rows are halved (half a tile
+    // always fits) and the parts follow one another; scores and corners accumulate.
+    constexpr int sc_shift = 3 * FP_W + cx0;
+    static_assert(FS_W == FP_W, "one offset addresses both tiles");
+    int row_lo = 0, row_hi = FS_H;
+    uint32_t n1_total = 0;   // pre-test passes of all parts (scene statistics)
+    static_assert(FQ1_N >= 2 * ((FS_H + 1) / 2) * (FT_W + 2), "half a tile's entries fit the first queue");
+    for (;;) {
     // stage 1: cardinal pre-test on the (FT_W+2) x (FT_H+2) region whose scores are needed,
     // four horizontally adjacent pixels per lane, one per byte.  v_lerp_u8 averages bytes
     // without carries between them: x = (a + (255 - b)) >> 1 (255 - b read from the inverted
@@ -401,11 +415,12 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         // dwords whatever the row, so no read of this stage meets a bank conflict (the three
         // dword columns per row outside the score region ride along with an empty column mask).
         static_assert(g0 >= 1 && g0 + ng < PD, "the left and right neighbour dwords stay inside the row");
-        for (int i0 = 0; i0 < PD * FS_H; i0 += 256) {
+        const int row_end = min(row_hi - 1, lim_y);   // last score row of this part
+        for (int i0 = PD * row_lo; i0 < PD * row_hi; i0 += 256) {
             const int i = i0 + tid;
             const int sy = i / PD, gi = i - sy * PD;
             uint32_t TD = 0, TB = 0;   // bits 7, 15, 23, 31: pixels 0..3 of the group pass (darker / brighter ring)
-            if (sy <= lim_y) {
+            if (sy <= row_end) {
                 const int idx = 3 * PD + i;
                 const uint32_t C = px32[idx];
                 const uint32_t Ci = ix32[idx], Li = ix32[idx - 1], Ri = ix32[idx + 1];
@@ -432,8 +447,8 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             uint32_t sl = (qb + upto - pc) << 1;   // byte offset of this lane's first entry
             const uint32_t pos = (uint32_t)((sy + 3) * FP_W + 4 * gi);
-            auto put = [&](uint32_t entry) {
-                *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(q1) + sl) = (uint16_t)entry;
+            auto put = [&](uint32_t entry) {   // (entries beyond the queue are dropped: the part is then run again in halves)
+                if (sl < 2u * (uint32_t)FQ1_N) *reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(q1) + sl) = (uint16_t)entry;
                 sl += 2u;
             };
             // one entry per passing pixel: the darker-ring copy if that polarity passed, else the plain one
@@ -449,10 +464,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
                 // four more ballot-and-compact rounds cost five times the instructions
                 if (both) {
                     uint32_t s = lds_fetch_add(&n1, (uint32_t)__popc(both));
-                    if (both & 0x80u) q1[s++] = (uint16_t)pos;
-                    if (both & 0x8000u) q1[s++] = (uint16_t)(pos + 1);
-                    if (both & 0x800000u) q1[s++] = (uint16_t)(pos + 2);
-                    if (both & 0x80000000u) q1[s] = (uint16_t)(pos + 3);
+                    auto put2 = [&](uint32_t entry) {
+                        if (s < (uint32_t)FQ1_N) q1[s] = (uint16_t)entry;
+                        ++s;
+                    };
+                    if (both & 0x80u) put2(pos);
+                    if (both & 0x8000u) put2(pos + 1);
+                    if (both & 0x800000u) put2(pos + 2);
+                    if (both & 0x80000000u) put2(pos + 3);
                 }
             }
         }
@@ -462,9 +481,14 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     // stage 2: the ring's largest 9-arc minimum against the centre, in the entry's polarity:
     // corner test and corner score at once (score (sy, sx) lives at the pixel's offset in the
     // plain tile minus sc_shift; at most one polarity of a pixel is a corner)
-    constexpr int sc_shift = 3 * FP_W + cx0;
-    static_assert(FS_W == FP_W, "one offset addresses both tiles");
     const uint32_t c1 = n1;
+    if (c1 > (uint32_t)FQ1_N) {   // (workgroup-uniform) the part did not fit: its first half, then the rest
+        __syncthreads();
+        if (tid == 0) n1 = 0;
+        row_hi = row_lo + (row_hi - row_lo + 1) / 2;
+        __syncthreads();
+        continue;
+    }
     for (uint32_t i0 = 0; i0 < c1; i0 += 256) {
         const uint32_t i = i0 + tid;
         bool pass = false;
@@ -479,6 +503,13 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
         wave_push(pass, (uint16_t)pos, q2, &n2, lane);
     }
     __syncthreads();
+    n1_total += c1;
+    if (row_hi >= FS_H) break;   // (workgroup-uniform)
+    row_lo = row_hi;
+    row_hi = FS_H;
+    if (tid == 0) n1 = 0;
+    __syncthreads();
+    }
     const uint32_t c2 = n2;
 
     // 3x3 non-max suppression + border filter on the interior (only corners need the look-up)
@@ -505,7 +536,7 @@ __global__ __launch_bounds__(256) void fast_kernel(Geom g, const uint8_t* __rest
     if (stats && tid == 0) {   // scene statistics (vo_debug_fast_stats), off in normal runs
         const int lim_x = min(FT_W + 1, max_sx), lim_y = min(FS_H - 1, max_sy);
         atomicAdd(&stats[0], (unsigned long long)((lim_x + 1) * (lim_y + 1)));
-        atomicAdd(&stats[1], (unsigned long long)n1);
+        atomicAdd(&stats[1], (unsigned long long)n1_total);
         atomicAdd(&stats[2], (unsigned long long)c2);
         atomicAdd(&stats[3], (unsigned long long)n);
     }
