@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // keypoint margin - gathering the 512 test points from global memory instead costs one L1 tag
 // look-up per lane and test), lane t evaluates tests t, t+32, ..., t+224 on it and eight
 // ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
-__global__ __launch_bounds__(256) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ blur,
+__global__ __launch_bounds__(256, 6) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ blur,
                                                        const vo_keypoint* __restrict__ kps,
                                                        const int32_t* __restrict__ counts, uint8_t* __restrict__ desc,
                                                        int cap) {
