@@ -131,8 +131,10 @@ __global__ void init_kernel(RState* __restrict__ st, const int32_t* __restrict__
 // dependent chains these kernels consist of.  (Scoring, bookkeeping and pose recovery keep the
 // translation unit's default - no contraction -, where an operation order is part of the result.)
 #pragma clang fp contract(fast)
-constexpr int ST = 16;   // lanes per solve workgroup (one hypothesis each): 25 KB of LDS, so a workgroup fits
-                         // beside the resident tiles of a concurrently running image kernel
+constexpr int ST = 32;   // lanes per solve workgroup (one hypothesis each): 51 KB of LDS, so three workgroups
+                         // share a CU, or one fits beside the resident tiles of an image kernel.  Sixteen lanes
+                         // (25 KB) left twice as many quarter-filled wavefronts issuing and measured 3 % slower
+                         // on the solve kernels; forty-eight measured no better than thirty-two.
 
 // quad[10] (+)= s * a[4] (x) b[4]
 __host__ __device__ __forceinline__ void mul_ll(const double* a, const double* b, double s, double* q) {
