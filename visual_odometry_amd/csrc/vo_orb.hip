@@ -1389,13 +1389,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
 }
 
-// rBRIEF descriptors from the finished keypoint records.  Half a wavefront per keypoint: the
+// rBRIEF descriptors from the finished keypoint records.  A wavefront takes `kpw` consecutive
+// keypoints (at most 64).  First every lane prepares one of them - window origin, row pitch, and
+// the (float) cosine and sine of its angle, evaluated in double: work that is the same for all
+// lanes of a keypoint and used to be repeated by each of them.  Then half a wavefront per keypoint: the
 // 37x37 blurred window around it goes to LDS with five 16-byte loads per lane (sweeps of
 // eight 64-byte rows; the columns wanted are inside the level thanks to the 31-px
 // keypoint margin - gathering the 512 test points from global memory instead costs one L1 tag
-// look-up per lane and test), lane t evaluates tests t, t+32, ..., t+224 on it and eight
-// ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
-__global__ __launch_bounds__(256, 6) void describe_kernel(Geom g, int bx, const uint8_t* __restrict__ blur,
+// look-up per lane and test), lane t evaluates tests t, t+32, ..., t+224 on it - both
+// coordinates of a rotated test point in one packed single-precision instruction per step - and
+// eight ballots give the 32 descriptor bytes (low word: first keypoint, high word: second).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256, 5) void describe_kernel(Geom g, int bx, int kpw, const uint8_t* __restrict__ blur,
                                                        const vo_keypoint* __restrict__ kps,
                                                        const int32_t* __restrict__ counts, uint8_t* __restrict__ desc,
                                                        int cap) {
@@ -1403,10 +1408,8 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(Geom g, int bx, const 
     if (!xcd_remap((uint32_t)bx * (uint32_t)g.n_images, &work)) return;
     const int img = (int)(work / (uint32_t)bx), blk = (int)(work - (uint32_t)img * (uint32_t)bx);
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = counts[img];
-    int pat[8];   // this lane's eight tests are the same for every keypoint
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pat[k] = reinterpret_cast<const int*>(d_pattern)[k * 32 + hl];
     const int r8 = hl >> 2, q16 = hl & 3;   // row of an eight-row sweep, 16-byte quarter of the 64-byte row
     const uint8_t* blur_img = blur + (size_t)img * g.blk_stride;
     // blurred window of +-18 px around the keypoint (the rotated test points stay inside:
@@ -1414,68 +1417,129 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(Geom g, int bx, const 
     // for it, pitch 80
     constexpr int DP_R = 18, DP_ROWS = 2 * DP_R + 1, DP_PITCH = 80;
     __shared__ __attribute__((aligned(16))) uint8_t patch[8][DP_ROWS * DP_PITCH];
-    uint8_t* my_patch = patch[(threadIdx.x >> 6) * 2 + half];
-    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
-        const bool live = o2 + half < n;
-        const int oi = live ? o2 + half : o2;
-        const vo_keypoint kp = kps[(size_t)img * cap + oi];
-        const LevelGeom& L = g.L[kp.octave];
-        const float inv = 1.f / L.scale;
-        const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
-        const int pitch = L.pitch;
-        // A load instruction costs the texture addresser about the same for 16 bytes per lane as
-        // for 4, and what it costs grows with the number of rows it touches: a row is fetched as
-        // four aligned 16-byte quarters (64 bytes from the 16-byte boundary at or below column
-        // cx - 18; rows of the blur block are 64-byte aligned), eight rows per half-wave and
-        // instruction, five instructions instead of thirteen dword sweeps.  The 37 columns
-        // wanted begin `skew` bytes into the 64.
-        const int skew = (cx - DP_R) & 15;
-        const uint32_t org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R - skew);
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 pw[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-            pw[t] = *reinterpret_cast<const u32x4*>(
-                blur_img + (org + (uint32_t)(__mul24(min(8 * t + r8, DP_ROWS - 1), pitch) + 16 * q16)));
-        const float ar = kp.angle * (float)(M_PI / 180.f);
-        double sd, cd;
-        sincos_f64((double)ar, &sd, &cd);
-        const float a = (float)cd, b = (float)sd;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous keypoint's reads are done
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-            if (8 * t + r8 < DP_ROWS) *reinterpret_cast<u32x4*>(&my_patch[(8 * t + r8) * DP_PITCH + 16 * q16]) = pw[t];
+    uint8_t* my_patch = patch[wave * 2 + half];
+    uint8_t* my_rows = my_patch + (r8 * DP_PITCH + 16 * q16);   // this lane's piece of sweep t: + 8 * t * DP_PITCH
+    const int row4 = min(32 + r8, DP_ROWS - 1);   // (the fifth sweep's rows 37..39 do not exist: clamped, not stored)
+    for (int o_base = (blk * 4 + wave) * kpw; o_base < n; o_base += bx * 4 * kpw) {
+        const int cnt = min(kpw, n - o_base);
+        // ---- one keypoint per lane
+        // (its values go to the 16 bytes that a 64-byte window row leaves unused in the 80-byte pitch:
+        // keypoint 2 i + h into row i of half h's window, where the window copies never write)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // cvRound of a rotated coordinate v, |v| < 2^22: the float sum v + 1.5 * 2^23 is rounded to
-        // an integer half-to-even like rint, and its bit pattern is 0x4B400000 + rint(v) - one
-        // fast-class add instead of v_rndne + v_cvt; the bias is folded into the window offset
-        // (the 24-bit multiply sees 0x400000 + row).
-        constexpr float kRound = 12582912.f;
-        const uint32_t cbase = (uint32_t)(DP_R * DP_PITCH + DP_R + skew) - 0x400000u * (uint32_t)DP_PITCH - 0x4B400000u;
-        auto tap = [&](float rx, float ry) -> int {
-            const uint32_t bx = __float_as_uint(rx + kRound), by = __float_as_uint(ry + kRound);
-            return my_patch[__umul24(by, (uint32_t)DP_PITCH) + bx + cbase];
+        {
+            uint32_t k_a, k_b, k_org, k_pitch;
+            const vo_keypoint kp = kps[(size_t)img * cap + o_base + min(lane, cnt - 1)];
+            const LevelGeom& L = g.L[kp.octave];
+            const float inv = 1.f / L.scale;
+            const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
+            const int pitch = L.pitch;
+            // A load instruction costs the texture addresser about the same for 16 bytes per lane as
+            // for 4, and what it costs grows with the number of rows it touches: a row is fetched as
+            // four aligned 16-byte quarters (64 bytes from the 16-byte boundary at or below column
+            // cx - 18; rows of the blur block are 64-byte aligned), eight rows per half-wave and
+            // instruction, five instructions instead of thirteen dword sweeps.  The 37 columns
+            // wanted begin `skew` = (cx - 18) & 15 bytes into the 64: the low four bits of the window's
+            // offset, because level offsets and pitches are multiples of 64.
+            k_org = L.off + (uint32_t)(__mul24(cy - DP_R, pitch) + cx - DP_R);
+            k_pitch = (uint32_t)pitch;
+            const float ar = kp.angle * (float)(M_PI / 180.f);
+            double sd, cd;
+            sincos_f64((double)ar, &sd, &cd);
+            k_a = __float_as_uint((float)cd);
+            k_b = __float_as_uint((float)sd);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4*>(&patch[wave * 2 + (lane & 1)][(lane >> 1) * DP_PITCH + 64]) = u32x4{k_a, k_b, k_org, k_pitch};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // This lane's eight tests, the same for every keypoint, are fetched here and not once per kernel
+        // (the opaque pointer keeps the compiler from moving the loads up): 32 registers that, held
+        // across the preparation above with its double-precision polynomials, exceed the budget of six
+        // wavefronts per SIMD and would be spilled for the whole kernel.
+        f32x2 p0[8], p1[8];
+        {
+            const int* patp = reinterpret_cast<const int*>(d_pattern);
+            asm volatile("" : "+s"(patp));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int pat = patp[k * 32 + hl];
+                p0[k] = f32x2{(float)(int8_t)(pat & 0xFF), (float)(int8_t)((pat >> 8) & 0xFF)};
+                p1[k] = f32x2{(float)(int8_t)((pat >> 16) & 0xFF), (float)(int8_t)(pat >> 24)};
+            }
+        }
+        // ---- half a wavefront per keypoint.  The loads of the next keypoint's window are issued as soon
+        // as the current one's have been written to LDS, so that they are in flight during its tests.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pw[5];
+        float a_nx, b_nx;
+        uint32_t skew_nx;
+        auto fetch = [&](int i) {
+            // (an idle second half repeats the first half's work and writes nothing)
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(&patch[wave * 2 + (2 * i + half < cnt ? half : 0)][i * DP_PITCH + 64]);
+            a_nx = __uint_as_float(kv.x);
+            b_nx = __uint_as_float(kv.y);
+            const uint32_t orgu = kv.z, pitch = kv.w;
+            skew_nx = orgu & 15u;
+            const uint32_t org0 = (orgu & ~15u) + 16u * (uint32_t)q16, pitch8 = 8u * pitch;
+            const uint32_t orgr = org0 + __umul24((uint32_t)r8, pitch);
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                pw[t] = *reinterpret_cast<const u32x4*>(
+                    blur_img + (t < 4 ? orgr + (uint32_t)t * pitch8 : org0 + __umul24((uint32_t)row4, pitch)));
         };
-        int t0[8], t1[8];
+        const int last = (cnt - 1) >> 1;
+        fetch(0);
+        for (int i = 0; i <= last; ++i) {
+            const bool live = 2 * i + half < cnt;     // an odd count leaves the last second half idle
+            const float a = a_nx, b = b_nx;
+            const uint32_t skew = skew_nx;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous keypoint's reads are done
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float x0 = (float)(int8_t)(pat[k] & 0xFF), y0 = (float)(int8_t)((pat[k] >> 8) & 0xFF);
-            float x1 = (float)(int8_t)((pat[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pat[k] >> 24);
-            float rx0 = x0 * a - y0 * b, ry0 = x0 * b + y0 * a;
-            float rx1 = x1 * a - y1 * b, ry1 = x1 * b + y1 * a;
-            t0[k] = tap(rx0, ry0);
-            t1[k] = tap(rx1, ry1);
-        }
-        uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
+            for (int t = 0; t < 5; ++t)
+                if (8 * t + r8 < DP_ROWS) *reinterpret_cast<u32x4*>(my_rows + 8 * t * DP_PITCH) = pw[t];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fetch(min(i + 1, last));   // (the last keypoint's once more: harmless, and no branch)
+            // cvRound of a rotated coordinate v, |v| < 2^22: the float sum v + 1.5 * 2^23 is rounded to
+            // an integer half-to-even like rint, and its bit pattern is 0x4B400000 + rint(v) - one
+            // fast-class add instead of v_rndne + v_cvt; the bias is folded into the window offset
+            // (the 24-bit multiply sees 0x400000 + row).
+            // (x a - y b, x b + y a) as (x, x) * (a, b) - (y, y) * (b, -a): the same products and the same
+            // sum or difference, rounded the same way, two coordinates per instruction
+            const f32x2 ab = {a, b}, nba = {b, -a};
+            const f32x2 kround = {12582912.f, 12582912.f};
+            const uint32_t cbase = (uint32_t)(DP_R * DP_PITCH + DP_R) + skew - 0x400000u * (uint32_t)DP_PITCH - 0x4B400000u;
+            // (the empty statements make the coordinate pairs opaque, so that the compiler selects its halves
+            // in the multiply - op_sel - instead of keeping (x, x) and (y, y) copies of every test point
+            // in registers across the loop, 64 instead of 32)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            unsigned long long m = __ballot(t0[k] < t1[k]);
-            uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-            if (hl == k) mine = w;
+            for (int k = 0; k < 8; ++k) {
+                asm volatile("" : "+v"(p0[k]));
+                asm volatile("" : "+v"(p1[k]));
+            }
+            auto tap = [&](f32x2 pt) -> int {
+                const f32x2 xx = __builtin_shufflevector(pt, pt, 0, 0), yy = __builtin_shufflevector(pt, pt, 1, 1);
+                const f32x2 r = (xx * ab - yy * nba) + kround;
+                return my_patch[__umul24(__float_as_uint(r.y), (uint32_t)DP_PITCH) + __float_as_uint(r.x) + cbase];
+            };
+            int t0[8], t1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                t0[k] = tap(p0[k]);
+                t1[k] = tap(p1[k]);
+            }
+            uint32_t mine = 0;   // lanes 0..7 of each half keep one ballot word each
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned long long m = __ballot(t0[k] < t1[k]);
+                uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+                if (hl == k) mine = w;
+            }
+            if (hl < 8 && live)
+                *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + (o_base + 2 * i + half)) * 32 + hl * 4) = mine;
         }
-        if (hl < 8 && live) *reinterpret_cast<uint32_t*>(desc + ((size_t)img * cap + oi) * 32 + hl * 4) = mine;
     }
 }
 
@@ -1855,8 +1919,14 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
                        (const uint32_t*)c->kp_cnt.p, d_kps, cap, d_counts, (uint32_t*)c->flags.p + c->flags_word,
                        c->img_status_cur);
     if (blur_aside) VO_HIP(c, hipStreamWaitEvent(s, c->ev_blur, 0));
+    // keypoints per wavefront of the descriptor kernel: sixteen amortise the per-wavefront set-up, eight keep
+    // the grid of a small call large enough to fill the GPU (64 per wavefront measured 20 % slower on 1024
+    // images of 2000 keypoints, 32 7 %: the kernel is bound by its LDS reads - 512 scattered bytes per
+    // keypoint - and long wavefronts only lengthen the tail)
+    const int kpw = (long long)N * ((g.max_features + 15) / 16) >= 4096 ? 16 : 8;
+    const int ddx = std::max((g.max_features + 4 * kpw - 1) / (4 * kpw), 1);
     if (d_desc)
-        hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)dbx * N)), dim3(256), 0, s, g, dbx,
+        hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid((uint32_t)ddx * N)), dim3(256), 0, s, g, ddx, kpw,
                            (const uint8_t*)c->blur.p, (const vo_keypoint*)d_kps, (const int32_t*)d_counts, d_desc, cap);
     t_end(c, VO_T_DESCRIBE);
     VO_HIP(c, hipGetLastError());
