@@ -1272,7 +1272,7 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
 // dword of the 32-byte row window); a step is two aligned LDS dwords shifted into place
 // (v_alignbyte), the disc byte mask and two v_dot4_u32_u8 (sum and column-weighted sum), the row
 // weight is applied to the row sum.  The first lane of the half writes the final keypoint.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint16_t* __restrict__ kp_x,
                                                      const uint16_t* __restrict__ kp_y,
@@ -1315,20 +1315,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     uint8_t* my_win = win[(threadIdx.x >> 6) * 2 + half];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (int o2 = (blk * 4 + (threadIdx.x >> 6)) * 2; o2 < n; o2 += bx * 8) {
-        const bool live = o2 + half < n;          // an odd count leaves the last second half idle
-        const int oi = live ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
+    // The levels' geometry, looked up per keypoint, comes from LDS: fetched from the kernel
+    // arguments with a per-lane level it is three dependent memory round trips per keypoint
+    // (candidate offset -> coordinates; level offset; pitch), and the kernel's time is the length of
+    // that chain.  For the same reason the next keypoint's coordinates and response are requested
+    // while the current window is on its way.
+    __shared__ u32x4 lvl[kLevels];   // candidate offset, byte offset of the level, pitch, scale
+    if (threadIdx.x < kLevels) {
+        const int k = threadIdx.x;
+        lvl[k] = u32x4{(uint32_t)g.L[k].kp_off, k ? (uint32_t)g.L[k].off : 0u, k ? (uint32_t)g.L[k].pitch : (uint32_t)g.step,
+                       __float_as_uint(g.L[k].scale)};
+    }
+    __syncthreads();
+    const uint8_t* base0 = in + (size_t)img * g.in_stride;
+    const uint8_t* base1 = pyr + (size_t)img * g.blk_stride;
+    const size_t ib0 = (size_t)img * g.kp_stride;
+    int l_nx = 0, oi_nx = 0, x_nx = 0, y_nx = 0;
+    bool live_nx = false;
+    float resp_nx = 0.f;
+    auto locate = [&](int o2) {
+        live_nx = o2 + half < n;              // an odd count leaves the last second half idle
+        oi_nx = live_nx ? o2 + half : o2;     // (it repeats the first half's work, writes nothing)
         int l = 0, lstart = 0;
 #pragma unroll
         for (int k = 1; k < kLevels; ++k) {
-            l += (oi >= start[k]);
-            lstart = (oi >= start[k]) ? start[k] : lstart;
+            l += (oi_nx >= start[k]);
+            lstart = (oi_nx >= start[k]) ? start[k] : lstart;
         }
-        const LevelGeom& L = g.L[l];
-        const size_t ib = (size_t)img * g.kp_stride + L.kp_off + (oi - lstart);
-        const int x = kp_x[ib], y = kp_y[ib];
-        int lpitch;
-        const uint8_t* lbase = level_base(g, in, pyr, img, l, &lpitch);
+        l_nx = l;
+        const size_t ib = ib0 + lvl[l].x + (uint32_t)(oi_nx - lstart);
+        x_nx = kp_x[ib];
+        y_nx = kp_y[ib];
+        resp_nx = kp_resp[ib];
+    };
+    const int o2_first = (blk * 4 + (threadIdx.x >> 6)) * 2;
+    if (o2_first < n) locate(o2_first);
+    for (int o2 = o2_first; o2 < n; o2 += bx * 8) {
+        const bool live = live_nx;
+        const int oi = oi_nx, l = l_nx, x = x_nx, y = y_nx;
+        const float resp = resp_nx;
+        const u32x4 lv = lvl[l];
+        const int lpitch = (int)lv.z;
+        const uint8_t* lbase = (l == 0 ? base0 : base1) + lv.y;
         // every address within 16 px of a keypoint is inside the level (keypoints keep a 31-px
         // margin); the 48 bytes of a row end at most one byte past column x + 16 + 15, still
         // inside the image buffer because the rows below the window exist
@@ -1339,6 +1367,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int t = 0; t < 3; ++t)
             __builtin_memcpy(&sv[t], p0 + (size_t)min(srow[t], OW_ROWS - 1) * lpitch + 16 * sseg[t], 16);
+        locate(o2 + bx * 8 < n ? o2 + bx * 8 : o2);   // (after the last keypoint its own once more: no branch,
+                                                      // so that the window loads can be waited for by count)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous keypoint's reads are done
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1376,12 +1406,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         m10 += __shfl_xor(m10, 16);
         m01 += __shfl_xor(m01, 16);
         if (hl == 0 && live) {
+            const float scale = __uint_as_float(lv.w);
             vo_keypoint k;
-            k.x = (float)x * L.scale;
-            k.y = (float)y * L.scale;
-            k.size = 31 * L.scale;
+            k.x = (float)x * scale;
+            k.y = (float)y * scale;
+            k.size = 31 * scale;
             k.angle = fast_atan2_deg((float)m01, (float)m10);
-            k.response = kp_resp[ib];
+            k.response = resp;
             k.octave = l;
             k.class_id = -1;
             kps[(size_t)img * cap + oi] = k;
