@@ -366,6 +366,44 @@ def test_orb_detect_when_the_pretest_queue_overflows(ctx, oracle):
 
 
 
+def test_orb_detect_batch_of_34_images_bit_exact(ctx, oracle):
+    """A device-resident batch large enough for the forms the kernels take on large calls (raised FAST
+    thresholds, sixteen keypoints per wavefront in the descriptor kernel - from 4096 wavefronts on, here
+    34 images x 125): every image's keypoints and descriptors are the oracle's, byte for byte.  The
+    images differ in content and in keypoint count (dense and sparse scenes, one nearly flat)."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for k in range(8):
+        frames.extend(synth.frame_pair(4100 + k))
+    for k in range(8):
+        frames.extend(synth.frame_pair(0x5EED0000 + 2100 + k, sparse=True, moving_fraction=0.6, n_layers=24))
+    flat = np.full((480, 640), 90, np.uint8)
+    flat[200:280, 300:420] = 160                      # four corners (on several levels) and nothing else
+    frames.extend([flat, frames[3][::-1].copy()])     # ... and an image turned upside down
+    n_img, cap = len(frames), 2000 + 8 * 256
+    assert n_img == 34
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    kps = torch.zeros(n_img * cap * capi.KP_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    desc = torch.zeros(n_img * cap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(n_img, dtype=torch.int32, device="cuda")
+    ctx.orb_detect_batch_dev(imgs.data_ptr(), n_img, 480, 640, 640, 480 * 640, 2000, kps.data_ptr(), desc.data_ptr(), cap,
+                             cnt.data_ptr())
+    ctx.sync()
+    assert ctx.fast_thresholds(0) is not None          # the batch is large enough for raised thresholds
+    counts = cnt.cpu().numpy()
+    gk = np.frombuffer(kps.cpu().numpy().tobytes(), capi.KP_DTYPE).reshape(n_img, cap)
+    gd = desc.cpu().numpy().reshape(n_img, cap, 32)
+    seen = set()
+    for i, img in enumerate(frames):
+        ok, od = oracle.orb_detect(img, 2000)
+        assert counts[i] == len(ok), i
+        assert gk[i, :len(ok)].tobytes() == ok.tobytes(), i
+        assert np.array_equal(gd[i, :len(ok)], od), i
+        seen.add(len(ok))
+    assert 2000 in seen and min(seen) < 64 and len(seen) >= 3   # full lists, a handful of keypoints, odd counts between
+
+
 @pytest.mark.parametrize("name,nfeat", [("synth640", 2000), ("synth640", 300), ("checker", 2000), ("kitti", 4000),
                                         ("odd", 500), ("narrow", 300), ("threshold", 800), ("sampled_strong", 2000),
                                         ("sampled_strong", 500)])
