@@ -17,6 +17,8 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--calls", type=int, default=600)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--sizes", default="1,2,3,5,8,12",
+                help="batch sizes to draw from (from 64 pairs of 2000 keypoints on, the kNN search runs on the tail stream too)")
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -27,7 +29,7 @@ K = synth.TUM_K
 rng = np.random.default_rng(args.seed)
 batches = []
 for b in range(7):
-    n = int(rng.choice([1, 2, 3, 5, 8, 12]))
+    n = int(rng.choice([int(v) for v in args.sizes.split(",")]))
     sparse = b % 3 == 1
     frames = []
     for p in range(n):

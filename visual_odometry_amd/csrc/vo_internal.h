@@ -214,7 +214,8 @@ int orb_run(vo_ctx* c, const uint8_t* d_imgs, vo_keypoint* d_kps, uint8_t* d_des
 // match
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2,
-                int nq_typical = 0);   // expected query count when nq_max is only a capacity (picks the workgroup size)
+                int nq_typical = 0,    // expected query count when nq_max is only a capacity (picks the workgroup size)
+                hipStream_t on = nullptr);   // a tail stream to run on instead of the main stream (see vo_pipeline.hip)
 int ratio_launch(vo_ctx* c, const int32_t* d_idx2, const int32_t* d_dist2, const int32_t* d_nq, int cnt_stride,
                  int nq_max, int batch,
                  float ratio, const vo_keypoint* d_kp1, const vo_keypoint* d_kp2, size_t kp_stride, int32_t* d_qidx,

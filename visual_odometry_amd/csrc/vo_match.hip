@@ -612,9 +612,12 @@ __global__ __launch_bounds__(256) void ratio_kernel(const int32_t* __restrict__ 
 
 int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stride, int nq_max, size_t q_stride, const uint8_t* d_t,
                 const int32_t* d_nt, int nt_max, size_t t_stride, int batch, int32_t* d_idx2, int32_t* d_dist2,
-                int nq_typical) {
+                int nq_typical, hipStream_t on) {
     if (nq_max <= 0 || batch <= 0) return VO_OK;
-    if (int jrc = join_tail(c)) return jrc;   // the table below may still be read by the previous batch's ratio test
+    // The table below may still be read by the previous batch's ratio test: the main stream waits for it.  (On a
+    // tail stream the search follows that test in stream order - table and stream belong to the same tail set.)
+    if (!on)
+        if (int jrc = join_tail(c)) return jrc;
     // The kernel: the matrix-core one unless VO_OPT_KNN_MODE says otherwise (0: the scalar-operand
     // vector kernel, 1: the vector kernel with the train rows broadcast from LDS; tuning and test aids).
     const int mode = c->opt[VO_OPT_KNN_MODE] < 0 ? 2 : c->opt[VO_OPT_KNN_MODE];
@@ -629,8 +632,8 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     }
     if (c->opt[VO_OPT_KNN_QUERIES_PER_LANE] > 0) qpl = c->opt[VO_OPT_KNN_QUERIES_PER_LANE];   // tuning aid
     dim3 grid((nq_max + 64 * qpl - 1) / (64 * qpl), batch);
-    hipStream_t s = c->stream;
-    t_begin(c, VO_T_KNN2);
+    hipStream_t s = on ? on : c->stream;
+    t_begin_on(c, VO_T_KNN2, s);
     if (qpl == 1 && mode >= 1) {
         // few workgroups (one large match): more wavefronts per workgroup, so that every SIMD
         // still has several to switch between.  Many (a batch of some hundred pairs): one
@@ -717,7 +720,7 @@ int knn2_launch(vo_ctx* c, const uint8_t* d_q, const int32_t* d_nq, int cnt_stri
     else
         hipLaunchKernelGGL(knn2_kernel<1>, grid, dim3(256), 0, s, d_q, d_nq, cnt_stride, nq_max, q_stride, d_t, d_nt, nt_max,
                            t_stride, d_idx2, d_dist2);
-    t_end(c, VO_T_KNN2);
+    t_end_on(c, VO_T_KNN2, s);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
