@@ -1128,6 +1128,50 @@ def test_estimate_motion_repeated_calls_agree(ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_pipeline_large_calls_equal_small_ones(ctx):
+    """From 64 pairs of 2000 keypoints on, a pipeline call enqueues its kNN search on the tail stream,
+    beside the next call's detection, instead of on the main stream.  Three such calls back to back
+    (70, 66 and 70 pairs, two record buffers) must give the records the same pairs give in calls of
+    seven, which keep the search on the main stream - also for the sequence form."""
+    import torch
+    from visual_odometry_amd import capi
+    frames = []
+    for p in range(70):
+        frames += list(synth.frame_pair(7000 + p) if p % 4 else
+                       synth.frame_pair(0x5EED0000 + 2300 + p, sparse=True, moving_fraction=0.6, n_layers=24))
+    imgs = torch.from_numpy(np.stack(frames)).cuda()
+    rec = capi.PAIR_DTYPE.itemsize
+    want = torch.zeros(70 * rec, dtype=torch.uint8, device="cuda")
+    for p0 in range(0, 70, 7):
+        ctx.pipeline_pairs_dev(imgs.data_ptr() + 2 * p0 * 480 * 640, 7, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0,
+                               0.999, 0, want.data_ptr() + p0 * rec)
+    ctx.sync()
+    want = np.frombuffer(want.cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    assert (want["valid"] == 1).all() and want["ransac_iters"].max() > 100 and want["ransac_iters"].min() < 40
+    bufs = [torch.zeros(70 * rec, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    plan = [(0, 70, 0), (4, 66, 1), (0, 70, 0)]   # (first pair, pairs, record buffer): the third overwrites the first's
+    for p0, n, b in plan:
+        ctx.pipeline_pairs_dev(imgs.data_ptr() + 2 * p0 * 480 * 640, n, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0,
+                               0.999, 0, bufs[b].data_ptr())
+    ctx.sync()
+    got0 = np.frombuffer(bufs[0].cpu().numpy().tobytes(), capi.PAIR_DTYPE)
+    got1 = np.frombuffer(bufs[1].cpu().numpy().tobytes(), capi.PAIR_DTYPE)[:66]
+    assert got0.tobytes() == want.tobytes()
+    assert got1.tobytes() == want[4:].tobytes()
+    # the sequence form: 140 frames -> 139 pairs in one call, against calls of at most 20 frames
+    seq_want = torch.zeros(139 * rec, dtype=torch.uint8, device="cuda")
+    for f0 in range(0, 139, 19):
+        nf = min(20, 140 - f0)
+        ctx.pipeline_sequence_dev(imgs.data_ptr() + f0 * 480 * 640, nf, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0,
+                                  0.999, 0, seq_want.data_ptr() + f0 * rec)
+    seq_got = torch.zeros(139 * rec, dtype=torch.uint8, device="cuda")
+    ctx.pipeline_sequence_dev(imgs.data_ptr(), 140, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                              seq_got.data_ptr())
+    ctx.sync()
+    assert seq_got.cpu().numpy().tobytes() == seq_want.cpu().numpy().tobytes()
+
+
+@pytest.mark.gpu
 def test_pipeline_graph_replay_equals_launches(ctx, options):
     """VO_OPT_PIPELINE_GRAPH: a pipeline call that repeats the previous one's arguments is captured
     as a HIP graph on its second occurrence and replayed from the third on.  Replays must give
