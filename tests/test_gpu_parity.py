@@ -1129,8 +1129,8 @@ def test_estimate_motion_repeated_calls_agree(ctx, oracle):
 
 @pytest.mark.gpu
 def test_pipeline_large_calls_equal_small_ones(ctx):
-    """From 64 pairs of 2000 keypoints on, a pipeline call enqueues its kNN search on the tail stream,
-    beside the next call's detection, instead of on the main stream.  Three such calls back to back
+    """Between 64 and 256 pairs of 2000 keypoints a pipeline call enqueues its kNN search on the tail
+    stream, beside the next call's detection, instead of on the main stream.  Three such calls back to back
     (70, 66 and 70 pairs, two record buffers) must give the records the same pairs give in calls of
     seven, which keep the search on the main stream - also for the sequence form."""
     import torch

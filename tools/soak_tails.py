@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--calls", type=int, default=600)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--sizes", default="1,2,3,5,8,12",
-                help="batch sizes to draw from (from 64 pairs of 2000 keypoints on, the kNN search runs on the tail stream too)")
+                help="batch sizes to draw from (between 64 and 256 pairs of 2000 keypoints the kNN search runs on the tail stream too)")
 args = ap.parse_args()
 
 import torch  # noqa: E402

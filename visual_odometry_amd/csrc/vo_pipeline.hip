@@ -185,16 +185,17 @@ static int pipeline_body(vo_ctx* c, const uint8_t* d_imgs, int n_images, int n_p
     VO_HIP(c, hipEventRecord(c->ev_in[ticket % VO_TICKET_RING], c->stream));
     // Everything after the kNN search - ratio test, counts, RANSAC rounds, pose recovery - is a
     // chain of small, latency-bound kernels: it goes to the side stream, so that the main stream
-    // can start the next batch's detection right behind the matcher.  On calls of some size the
-    // search goes there as well and runs beside the next batch's resize chain and first FAST launch
-    // (measured in alternating runs on one box: 64 pairs of 2000 keypoints +3.7 %, 256 +2.5 %, 512
-    // +0.1 % on the dense scene and +1.6 % on the sparse one, 32 full-HD pairs +1.3 %; 100-pair
-    // sequences of 1000 keypoints, which are a chain of short launches, -4 %: those keep it on the
-    // main stream).  ev_tail marks the point after which the side stream no longer reads this
-    // batch's keypoints, descriptors and kNN table; the next batch's orientation kernel, the first
-    // to overwrite any of them, waits for it.
+    // can start the next batch's detection right behind the matcher.  On calls of middling size
+    // the search goes there as well and runs beside the next batch's resize chain and first FAST
+    // launch (measured in alternating runs on one box: 64 pairs of 2000 keypoints +3.7 %, 256
+    // +2.5 %, 256 pairs of 4000 keypoints +1 %, 32 full-HD pairs +1.3 %).  Not on the smallest
+    // (100-pair sequences of 1000 keypoints, a chain of short launches: -4 %) and not on the
+    // largest: 512 dense pairs fill the GPU either way (+0.1 %) and only stretch the FAST launch
+    // that the search then shares it with.  ev_tail marks the point after which the side stream
+    // no longer reads this batch's keypoints, descriptors and kNN table; the next batch's
+    // orientation kernel, the first to overwrite any of them, waits for it.
     hipStream_t side = c->side;
-    const bool search_aside = (long long)n_pairs * max_features >= 128000;
+    const bool search_aside = (long long)n_pairs * max_features >= 128000 && n_pairs <= 256;
     const size_t dstride = (size_t)pair_step * cap * 32;
     if (!search_aside &&
         (rc = knn2_launch(c, desc, cnt, pair_step, cap, dstride, desc + (size_t)cap * 32, cnt + 1, cap, dstride, n_pairs,
