@@ -1272,7 +1272,7 @@ __device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
 // dword of the 32-byte row window); a step is two aligned LDS dwords shifted into place
 // (v_alignbyte), the disc byte mask and two v_dot4_u32_u8 (sum and column-weighted sum), the row
 // weight is applied to the row sum.  The first lane of the half writes the final keypoint.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void orient_kernel(Geom g, int bx, const uint8_t* __restrict__ in,
                                                      const uint8_t* __restrict__ pyr,
                                                      const uint16_t* __restrict__ kp_x,
                                                      const uint16_t* __restrict__ kp_y,
@@ -1300,9 +1300,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
     const int n = min(total, cap);
-    uint32_t amask[8];   // this lane's disc masks are the same for every keypoint
-#pragma unroll
-    for (int k = 0; k < 8; ++k) amask[k] = d_angle_mask[k * 32 + hl];
+    // this lane's disc masks, the same for every keypoint, are read from LDS in the loop: eight
+    // registers less are a seventh wavefront per SIMD, and the kernel waits for loads, not for LDS
+    __shared__ uint32_t amask_l[8 * 32];
+    amask_l[threadIdx.x] = d_angle_mask[threadIdx.x];
     const int rr = hl >> 3, dj = hl & 7;
     const uint32_t wcol = 0x03020100u + 0x04040404u * (uint32_t)dj;   // window byte index = u + 15
     // staging: element i = 32 * t + hl of the 31 x 3 sixteen-byte pieces, row i / 3, piece i % 3
@@ -1385,7 +1386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         for (int t = 0; t < 8; ++t) {
             // (rows 31 of the last step do not exist: their mask is empty, the address is clamped)
             const uint32_t* q = wp + min(4 * t, OW_ROWS - 1 - rr) * (OW_PITCH / 4);
-            uint32_t val = __builtin_amdgcn_alignbyte(q[1], q[0], sh) & amask[t];
+            uint32_t val = __builtin_amdgcn_alignbyte(q[1], q[0], sh) & amask_l[t * 32 + hl];
             uint32_t rs = __builtin_amdgcn_udot4(val, 0x01010101u, 0u, false);
             X = __builtin_amdgcn_udot4(val, wcol, X, false);
             S += rs;
