@@ -1128,7 +1128,7 @@ def test_estimate_motion_repeated_calls_agree(ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_pipeline_large_calls_equal_small_ones(ctx):
+def test_pipeline_large_calls_equal_small_ones(ctx, options):
     """Between 64 and 256 pairs of 2000 keypoints a pipeline call enqueues its kNN search on the tail
     stream, beside the next call's detection, instead of on the main stream.  Three such calls back to back
     (70, 66 and 70 pairs, two record buffers) must give the records the same pairs give in calls of
@@ -1158,6 +1158,15 @@ def test_pipeline_large_calls_equal_small_ones(ctx):
     got1 = np.frombuffer(bufs[1].cpu().numpy().tobytes(), capi.PAIR_DTYPE)[:66]
     assert got0.tobytes() == want.tobytes()
     assert got1.tobytes() == want[4:].tobytes()
+    # the opt-in graph replay of such a call (captured on its second occurrence, replayed on the third)
+    options("pipeline_graph", 1)
+    for rep in range(3):
+        bufs[0].zero_()
+        ctx.pipeline_pairs_dev(imgs.data_ptr(), 70, 480, 640, 640, 480 * 640, 2000, 0.75, TUM_K, 1.0, 0.999, 0,
+                               bufs[0].data_ptr())
+        ctx.sync()
+        assert bufs[0].cpu().numpy().tobytes() == want.tobytes(), rep
+    options("pipeline_graph", 0)
     # the sequence form: 140 frames -> 139 pairs in one call, against calls of at most 20 frames
     seq_want = torch.zeros(139 * rec, dtype=torch.uint8, device="cuda")
     for f0 in range(0, 139, 19):
